@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the fused Airbot-cube env step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One process per GPU; every rank owns `--envs` (default 8192) environments, i.e. the env batch is sharded
+by index with per-GPU work fixed ("weak" scaling).  A step = one `rsr_step` launch =
+AutoReset/Episode wrappers + ctrl shaping + 4 physics substeps + reward/obs for every env of the rank.
+Inputs (state records, per-env domain-randomised model leaves, K pre-generated action tensors) are resident
+in HBM before the timed region.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES_S = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
+BYTES_PER_ENV_STEP_DR = 1220       # algorithmic bytes per env-step, Airbot cube with DR
+BYTES_PER_ENV_STEP = 728           # ... without DR
+
+
+def cpu_baseline(blob: bytes, dr, seconds: float = 12.0):
+    """The CPU oracle (kind "port") timed on all host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from rsr_mjx_amd import prng
+    O.build()
+    orc = O.Oracle(blob)
+    threads = orc.max_threads()
+    n = 1024
+    sub = None if dr is None else {k: np.ascontiguousarray(v[:n]) for k, v in dr.items()}
+    st = orc.new_state(n, sub)
+    orc.reset(st, prng.split(prng.PRNGKey(123), n), threads)
+    rng = np.random.default_rng(1)
+    acts = np.clip(rng.normal(size=(8, n, 5)), -1, 1).astype(np.float32)
+    for i in range(3):
+        orc.step(st, acts[i], threads)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        orc.step(st, acts[k % 8], threads)
+        k += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n * k / dt, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"oracle/rsr_oracle.c (fp32, OpenMP) on {n} envs x {k} steps of the same workload, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
+    ap.add_argument("--no-dr", action="store_true", help="disable domain randomisation")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.distributed import gather_metrics, shard_keys, shard_range
+    from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    total = n * world
+    # global key fan-out, sliced per rank so results do not depend on the GPU count (RSR/train.py:232-235)
+    key_env = prng.split(prng.PRNGKey(0), 3)[1]
+    lo, hi = shard_range(total, rank, world)
+    keys = shard_keys(key_env, total, rank, world)
+    envdef = AirbotPlayBase(device=f"cuda:{local_rank}")
+    dr = None if args.no_dr else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), total)[lo:hi])
+    env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)   # train.py:47-50
+    state = env.reset(keys)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    npool = min(args.steps, 256)
+    actions = torch.clamp(torch.randn((npool, n, 5), generator=gen, device=dev), -1.0, 1.0)
+    metrics = torch.zeros(4, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        env.step(state, actions[i % npool])
+    barrier()
+    env.timing_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step(state, actions[i % npool])
+    kernel_ms, launches = env.timing_end()      # HIP events on the launch stream; also synchronises it
+    # end-of-rollout metric gather (the path's only collective)
+    metrics[0] = float(args.steps * n)
+    metrics[1] = state.reward.sum()
+    metrics[2] = state.done.sum()
+    metrics[3] = state.info["episode_metrics"]["sum_reward"].mean()
+    metrics_all = gather_metrics(metrics)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    env_steps = float(metrics_all[:, 0].sum().item())
+
+    if rank == 0:
+        bytes_per = BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR
+        avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+        achieved = bytes_per * n / avg_launch_s
+        stats = env.view("stats").float().mean(dim=0).tolist()
+        out = {
+            "metric": "env-steps/sec at num_envs=8192, Airbot cube",
+            "value": env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"AirbotPlayBase cube_env, num_envs={n} per GPU ({total} total), episode_length=1200, "
+                            f"auto-reset, domain randomisation {'off' if args.no_dr else 'on'}, 4 substeps/env-step, "
+                            "actions N(0,1) clipped to +-1",
+                "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
+                "kernel": "rsr::step_kernel<CubeDims> (one wavefront per env)",
+                "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
+                "mean_newton_iters_last_substep": stats[0], "mean_linesearch_iters_last_substep": stats[1],
+                "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_BYTES_S, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per * n, "avg_launch_ms": avg_launch_s * 1e3,
+                "note": "state stays on-chip for the whole step, so the path is VALU/LDS-latency bound, not HBM bound "
+                        "(SURVEY.md 8d); the fraction is reported because the metric names it",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env.blob, dr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+/*
+ * rsr_mjx.h -- C ABI of the MI355X-native batched env stepper (librsrmjx.so).
+ *
+ * The reference has no FFI on this path: the boundary is a Python object protocol traced by JAX
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it stands in for:
+ *
+ *   rsr_model_create  <- env construction: mujoco.MjModel.from_xml_path + mjcf.load_model
+ *                        (reference ppo_train/airbot_training/cube_env.py:37-43).  The MJCF compile
+ *                        itself is host Python (rsr_mjx_amd/mjcf.py); the result crosses the ABI as
+ *                        one flat "RSRM" blob of named float32/int32 arrays (rsr_mjx_amd/model.py).
+ *   rsr_batch_create  <- envs.training.wrap(env, episode_length, action_repeat, randomization_fn)
+ *                        + the vmapped state allocation (reference RSR/train.py:224-235)
+ *   rsr_batch_set_dr  <- DomainRandomizationVmapWrapper's per-env model leaves
+ *                        (reference ppo_train/airbot_training/domain_randomize.py:63-90)
+ *   rsr_reset         <- jit(vmap(env.reset))(key_envs)      (RSR/train.py:231-235, cube_env.py:95-143)
+ *   rsr_step          <- env.step(state, action) under AutoReset(Episode(Vmap(env)))
+ *                        (RSR/train.py:313-319 via acting.generate_unroll; cube_env.py:145-213)
+ *   rsr_view          <- reading fields of the returned State pytree (cube_env.py:143, 211-213)
+ *
+ * Conventions: every function returns 0 on success and a negative code on error;
+ * rsr_last_error() returns a thread-local message.  No exceptions cross the ABI.  Handles are opaque
+ * and destroyed by the caller.  All device pointers are HIP device pointers on the batch's device.
+ * rsr_reset / rsr_step are asynchronous on the given hipStream_t (NULL = default stream).
+ * A batch handle is thread-compatible, not thread-safe.  There is no CPU fallback: without a HIP
+ * device every compute entry point fails with RSR_ERR_HIP.
+ */
+#ifndef RSR_MJX_H_
+#define RSR_MJX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsr_model rsr_model;
+typedef struct rsr_batch rsr_batch;
+
+enum {
+  RSR_OK = 0,
+  RSR_ERR_ARG = -1,       /* bad argument / malformed blob */
+  RSR_ERR_UNSUPPORTED = -2, /* model dims or env kind the kernels are not built for */
+  RSR_ERR_HIP = -3,       /* HIP runtime error (message has the hipError string) */
+  RSR_ERR_NOMEM = -4
+};
+
+typedef struct rsr_dims {
+  int32_t nq, nv, nu, nbody, njnt, ngeom, nsite, neq, npair;
+  int32_t obs_dim, nmetrics, n_frames, episode_length, env_kind;
+  int32_t rec_floats;        /* floats per env in the persistent state record */
+  int32_t ncon_max, nefc_max; /* per-env active-contact / constraint-row capacity of the kernel */
+  int32_t lds_bytes;         /* LDS bytes per wavefront (= per env) of the step kernel */
+} rsr_dims;
+
+/* Fields of the per-env state record, for rsr_view.  Names follow the reference State pytree. */
+enum rsr_field {
+  RSR_F_QPOS = 0, RSR_F_QVEL, RSR_F_CTRL, RSR_F_QACC_WARMSTART, RSR_F_TIME, RSR_F_XPOS, RSR_F_SITE_XPOS,
+  RSR_F_OBS, RSR_F_REWARD, RSR_F_DONE, RSR_F_METRICS,
+  RSR_F_INFO_TARGET_POS, RSR_F_INFO_NEW_CUBE_POS, RSR_F_INFO_SITE_POS, RSR_F_INFO_CUBE_POS,
+  RSR_F_INFO_STEPS, RSR_F_INFO_TRUNCATION, RSR_F_INFO_EPISODE_DONE, RSR_F_INFO_EPISODE_METRICS,
+  RSR_F_FIRST_QPOS, RSR_F_FIRST_QVEL, RSR_F_FIRST_CTRL, RSR_F_FIRST_WARMSTART, RSR_F_FIRST_TIME,
+  RSR_F_FIRST_XPOS, RSR_F_FIRST_SITE_XPOS, RSR_F_FIRST_OBS,
+  RSR_F_STATS,             /* int32[4]: solver iters, line-search iters, active contacts, dropped contacts */
+  RSR_F_COUNT
+};
+
+/* Model + env configuration from an RSRM blob (host memory; copied). */
+int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out);
+int rsr_model_dims(const rsr_model* m, rsr_dims* out);
+void rsr_model_destroy(rsr_model* m);
+
+/* A batch of num_envs env records on HIP device `hip_device`.
+ * `state` may be NULL (the library allocates num_envs*rec_floats floats) or a caller-owned device
+ * buffer of that size (e.g. a torch tensor) which must outlive the batch. */
+int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device, float* state, rsr_batch** out);
+void rsr_batch_destroy(rsr_batch* b);
+
+/* Per-env model overrides, device pointers [num_envs, ngeom*3], [num_envs, nbody], [num_envs, nv],
+ * [num_envs, nv]; any may be NULL (= the model's value for every env).  Pointers are borrowed. */
+int rsr_batch_set_dr(rsr_batch* b, const float* geom_friction, const float* body_mass,
+                     const float* dof_damping, const float* dof_frictionloss);
+
+/* keys: device uint32 [num_envs, 2] (jax.random key data).  Writes every record field. */
+int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream);
+
+/* action: device float32 [num_envs, nu].  One fused launch: AutoReset pre-step, env prologue,
+ * n_frames physics substeps, epilogue (reward/done/obs/metrics/info), Episode + AutoReset post-step. */
+int rsr_step(rsr_batch* b, const float* action, void* hip_stream);
+
+/* Zero-copy strided view of one record field: element (e, i) is at dev_ptr[e*stride[0] + i*stride[1]]
+ * (strides in elements of 4 bytes); shape[0] = num_envs, shape[1] = field width. */
+int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shape[2], int64_t stride[2]);
+
+/* Optional per-stage dump for parity debugging: device float buffer [num_envs, RSR_DEBUG_FLOATS]
+ * filled by the next rsr_step/rsr_reset from the LAST physics forward pass (NULL disables). */
+#define RSR_DEBUG_FLOATS 8192
+int rsr_batch_set_debug(rsr_batch* b, float* dev_buffer);
+
+/* Average kernel time in ms of the last `rsr_step` launches recorded between rsr_timing_begin/end
+ * with HIP events on the stream the kernels were launched on. */
+int rsr_timing_begin(rsr_batch* b, void* hip_stream);
+int rsr_timing_end(rsr_batch* b, void* hip_stream, float* total_ms, int* launches);
+
+const char* rsr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSR_MJX_H_ */

@@ -1,0 +1,835 @@
+// rsr_device.hpp -- device-side physics for the fused env step, written for gfx950 (CDNA4) only.
+//
+// Execution model: ONE 64-lane wavefront owns ONE environment for the whole step (prologue,
+// n_frames physics substeps, epilogue).  The env's state, kinematic tiles, mass matrix, contact list
+// and constraint Jacobian live in LDS for the whole step; per-dof vectors live in lane i's registers
+// (lane = dof), per-constraint-row scalars in lane r's registers (lane = row mod 64), the rows of the
+// mass matrix / Newton Hessian in lane i's registers for an in-register Cholesky that talks across
+// lanes with v_readlane only.  HBM is touched once to load the record and once to store it.
+// MFMA is not used: the per-env matrices are 20x20 with ragged active-row counts.
+//
+// The stages restate MJX's forward/step; the tree recursions of the
+// reference (scan.body_tree) are replaced by per-lane loops over precomputed ancestor / subtree
+// bitmasks (rsr_mjx_amd/model.py: topology_tables), which removes the serial dependency chains.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsr {
+
+#define RSR_MINVAL 1e-15f
+#define RSR_MINIMP 0.0001f
+#define RSR_MAXIMP 0.9999f
+
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { PAIR_PLANE_BOX = 0, PAIR_BOX_BOX = 1, PAIR_PLANE_SPHERE = 2, PAIR_HFIELD_SPHERE = 3 };
+enum { INT_EULER = 0, INT_IMPLICITFAST = 3 };
+enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
+
+// ---- device view of the model blob (pointers into one device copy of the blob) ----
+struct DModel {
+  const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
+  const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
+  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited, *jnt_actfrclimited;
+  const float *jnt_pos, *jnt_axis, *jnt_range, *jnt_actfrcrange, *jnt_solref, *jnt_solimp, *jnt_margin;
+  const int *dof_bodyid, *dof_jntid;
+  const unsigned *dof_ancmask, *dof_velmask, *body_dofmask, *body_submask;
+  const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
+  const int *geom_bodyid, *geom_priority;
+  const float *geom_size, *geom_pos, *geom_quat, *geom_friction;
+  const int *site_bodyid;
+  const float *site_pos;
+  const int *eq_obj1id, *eq_obj2id, *eq_active0;
+  const float *eq_data, *eq_solref, *eq_solimp;
+  const int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
+  const float *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
+  const int *pair_geom1, *pair_geom2, *pair_kind, *pair_condim;
+  const float *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
+  const int *fric_dofs, *limit_jnts;
+  const float *qpos0;
+  const int *env_ids;
+  const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
+  float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
+  int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
+  int nfric, nlimit;
+  int env_kind, n_frames, episode_length, wrap_flags;
+};
+
+// ---- record layout (floats per env); offsets filled on the host, see rsr_mjx.hip ----
+struct Layout {
+  int qpos, qvel, ctrl, warm, time, xpos, site_xpos;
+  int obs, reward, done, metrics;
+  int target_pos, new_cube_pos, site_pos, cube_pos, steps, truncation, episode_done, episode_metrics;
+  int f_qpos, f_qvel, f_ctrl, f_warm, f_time, f_xpos, f_site_xpos, f_obs;
+  int stats;
+  int rec;            // floats per env (multiple of 16)
+  int persist_end;    // [0, persist_end) = pipeline state restored by auto-reset (qpos..site_xpos)
+};
+
+struct StepArgs {
+  float* state;                 // [N][rec]
+  const float* action;          // [N][nu]         (step)
+  const uint32_t* keys;         // [N][2]          (reset)
+  const float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;   // [N][...] or null
+  float* debug;                 // [N][RSR_DEBUG_FLOATS] or null
+  int n;
+};
+
+// ---- compile-time dimensions of one model family ----
+template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
+          int NCON_, int OBS_, int NMET_>
+struct Dims {
+  static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
+  static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
+  static constexpr int LD = NV_ + 1;                        // padded row stride: conflict-free row and column reads
+  static constexpr int NEFC = NEQ_ + NF_ + NL_ + 6 * NCON_;   // constraint-row capacity
+  static constexpr int NCHUNK = (NEFC + 63) / 64;           // rows per lane
+};
+
+// ---- tiny vector helpers ----
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ Q4 ld4(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void st4(float* p, Q4 q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return Q4{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+struct M33 { float m[9]; };
+__device__ __forceinline__ M33 q2m(Q4 q) {
+  M33 r;
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  r.m[0] = w * w + x * x - y * y - z * z; r.m[1] = 2 * (x * y - w * z); r.m[2] = 2 * (x * z + w * y);
+  r.m[3] = 2 * (x * y + w * z); r.m[4] = w * w - x * x + y * y - z * z; r.m[5] = 2 * (y * z - w * x);
+  r.m[6] = 2 * (x * z - w * y); r.m[7] = 2 * (y * z + w * x); r.m[8] = w * w - x * x - y * y + z * z;
+  return r;
+}
+__device__ __forceinline__ V3 mulv(const M33& m, V3 v) {
+  return V3{m.m[0] * v.x + m.m[1] * v.y + m.m[2] * v.z, m.m[3] * v.x + m.m[4] * v.y + m.m[5] * v.z,
+            m.m[6] * v.x + m.m[7] * v.y + m.m[8] * v.z};
+}
+__device__ __forceinline__ V3 mulv(const float* m, V3 v) {
+  return V3{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+__device__ __forceinline__ V3 col(const float* m, int c) { return V3{m[c], m[3 + c], m[6 + c]}; }
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) { return mulv(q2m(q), v); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// ---- wave helpers (wave64) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#define WSYNC() __syncthreads()
+
+// ---- LDS image of one environment ----
+template <class C>
+struct Smem {
+  // state + per-env model overrides
+  float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
+  float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
+  // position stage
+  float xpos[C::NB * 3], xquat[C::NB * 4], xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
+  float xanchor[C::NJ * 3], xaxis[C::NJ * 3];
+  float gpos[C::NG * 3], gmat[C::NG * 9], spos[C::NS * 3];
+  float com[C::NB * 3], cinert[C::NB * 10], crb[C::NB * 10], cdof[C::NV * 6], cdofdot[C::NV * 6];
+  float cvel[C::NB * 6], cacc[C::NB * 6], cfrc[C::NB * 6], cfrcsum[C::NB * 6];
+  float M[C::NV * C::LD], T[C::NV * C::LD];
+  float vq[C::NV];                                   // broadcast buffer for one per-dof vector
+  // contacts (active only)
+  float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
+  int cpair[C::NCON];
+  int ncon, ncon_drop, nlim_act;
+  int lim_jnt[C::NL > 0 ? C::NL : 1];
+  // constraint rows; the clip scratch of the collision stage aliases J
+  float J[C::NEFC * C::LD];
+  float rw[C::NEFC];                                 // per-row weight D*active (Hessian), then force (J^T f)
+};
+
+// =====================================================================================
+// stage 1: kinematics (MJX smooth.kinematics).  The chain is serial; every lane walks it
+// redundantly (wave-uniform control flow, scalar model loads), lane 0 publishes to LDS.
+// =====================================================================================
+template <class C>
+__device__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
+  if (lane == 0) { st3(s.xpos, v3(0, 0, 0)); st4(s.xquat, Q4{1, 0, 0, 0}); }
+  WSYNC();
+  for (int b = 1; b < C::NB; ++b) {
+    int p = m.body_parentid[b];
+    Q4 pq = ld4(&s.xquat[4 * p]);
+    V3 pos = ld3(&s.xpos[3 * p]) + qrot(pq, ld3(&m.body_pos[3 * b]));
+    Q4 q = qmul(pq, ld4(&m.body_quat[4 * b]));
+    int jn = m.body_jntnum[b], ja0 = m.body_jntadr[b];
+    for (int k = 0; k < jn; ++k) {
+      int j = ja0 + k, qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
+      if (jt == JNT_FREE) {
+        pos = ld3(&s.qpos[qa]);
+        q = ld4(&s.qpos[qa + 3]);
+        float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+        if (n < RSR_MINVAL) q = Q4{1, 0, 0, 0};
+        else { float inv = 1.0f / n; q = Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv}; }
+        if (lane == 0) { st3(&s.xanchor[3 * j], pos); st3(&s.xaxis[3 * j], v3(0, 0, 1)); st4(&s.qpos[qa + 3], q); }
+      } else {
+        V3 jp = ld3(&m.jnt_pos[3 * j]), jax = ld3(&m.jnt_axis[3 * j]);
+        V3 anchor = qrot(q, jp) + pos, axis = qrot(q, jax);
+        if (lane == 0) { st3(&s.xanchor[3 * j], anchor); st3(&s.xaxis[3 * j], axis); }
+        float dq = s.qpos[qa] - m.qpos0[qa];
+        if (jt == JNT_HINGE) {
+          float sn, cs;
+          sincosf(dq * 0.5f, &sn, &cs);
+          q = qmul(q, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
+          pos = anchor - qrot(q, jp);
+        } else {
+          pos = pos + axis * dq;
+        }
+      }
+    }
+    if (lane == 0) { st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q); }
+    WSYNC();
+  }
+  // frames of bodies / inertial frames / geoms / sites: one lane each
+  if (lane < C::NB) {
+    int b = lane;
+    Q4 q = ld4(&s.xquat[4 * b]);
+    M33 R = q2m(q);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.xmat[9 * b + c] = R.m[c];
+    st3(&s.xipos[3 * b], ld3(&s.xpos[3 * b]) + mulv(R, ld3(&m.body_ipos[3 * b])));
+    M33 Ri = q2m(qmul(q, ld4(&m.body_iquat[4 * b])));
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.ximat[9 * b + c] = Ri.m[c];
+  }
+  if (lane < C::NG) {
+    int g = lane, b = m.geom_bodyid[g];
+    Q4 q = ld4(&s.xquat[4 * b]);
+    M33 R = q2m(q);
+    st3(&s.gpos[3 * g], ld3(&s.xpos[3 * b]) + mulv(R, ld3(&m.geom_pos[3 * g])));
+    M33 Rg = q2m(qmul(q, ld4(&m.geom_quat[4 * g])));
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.gmat[9 * g + c] = Rg.m[c];
+  }
+  if (lane < C::NS) {
+    int b = m.site_bodyid[lane];
+    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * b]) + qrot(ld4(&s.xquat[4 * b]), ld3(&m.site_pos[3 * lane])));
+  }
+  WSYNC();
+}
+
+// spatial inertia (10-vector: xx yy zz xy xz yz, m*off(3), m) times motion vector (ang, lin)
+__device__ __forceinline__ void inert_mul(float* o, const float* i, const float* v) {
+  V3 p = ld3(i + 6), va = ld3(v), vl = ld3(v + 3);
+  V3 t = cross(p, vl);
+  o[0] = i[0] * va.x + i[3] * va.y + i[4] * va.z + t.x;
+  o[1] = i[3] * va.x + i[1] * va.y + i[5] * va.z + t.y;
+  o[2] = i[4] * va.x + i[5] * va.y + i[2] * va.z + t.z;
+  V3 u = cross(p, va);
+  o[3] = i[9] * vl.x - u.x; o[4] = i[9] * vl.y - u.y; o[5] = i[9] * vl.z - u.z;
+}
+
+// =====================================================================================
+// stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
+// =====================================================================================
+template <class C>
+__device__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
+  // subtree centre of mass: lane b sums its subtree
+  if (lane < C::NB) {
+    unsigned mask = m.body_submask[lane];
+    float mm = 0; V3 acc = v3(0, 0, 0);
+    while (mask) {
+      int k = __builtin_ctz(mask); mask &= mask - 1;
+      float mk = s.mass[k];
+      mm += mk; acc = acc + ld3(&s.xipos[3 * k]) * mk;
+    }
+    V3 c = mm < RSR_MINVAL ? ld3(&s.xipos[3 * lane]) : acc * (1.0f / mm);
+    st3(&s.com[3 * lane], c);
+  }
+  WSYNC();
+  if (lane < C::NB) {
+    int b = lane;
+    const float* R = &s.ximat[9 * b];
+    V3 off = ld3(&s.xipos[3 * b]) - ld3(&s.com[3 * m.body_rootid[b]]);
+    float I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2], ms = s.mass[b];
+    float* ci = &s.cinert[10 * b];
+    ci[0] = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2] + ms * (off.y * off.y + off.z * off.z);
+    ci[1] = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5] + ms * (off.x * off.x + off.z * off.z);
+    ci[2] = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8] + ms * (off.x * off.x + off.y * off.y);
+    ci[3] = R[0] * I0 * R[3] + R[1] * I1 * R[4] + R[2] * I2 * R[5] - ms * off.x * off.y;
+    ci[4] = R[0] * I0 * R[6] + R[1] * I1 * R[7] + R[2] * I2 * R[8] - ms * off.x * off.z;
+    ci[5] = R[3] * I0 * R[6] + R[4] * I1 * R[7] + R[5] * I2 * R[8] - ms * off.y * off.z;
+    ci[6] = ms * off.x; ci[7] = ms * off.y; ci[8] = ms * off.z; ci[9] = ms;
+  }
+  // cdof: lane = dof
+  if (lane < C::NV) {
+    int i = lane, j = m.dof_jntid[i], b = m.dof_bodyid[i], jt = m.jnt_type[j], k = i - m.jnt_dofadr[j];
+    V3 off = ld3(&s.com[3 * m.body_rootid[b]]) - ld3(&s.xanchor[3 * j]);
+    V3 ang, lin;
+    if (jt == JNT_FREE) {
+      if (k < 3) { ang = v3(0, 0, 0); lin = v3(k == 0, k == 1, k == 2); }
+      else { ang = col(&s.xmat[9 * b], k - 3); lin = cross(ang, off); }
+    } else if (jt == JNT_HINGE) { ang = ld3(&s.xaxis[3 * j]); lin = cross(ang, off); }
+    else { ang = v3(0, 0, 0); lin = ld3(&s.xaxis[3 * j]); }
+    st3(&s.cdof[6 * i], ang); st3(&s.cdof[6 * i + 3], lin);
+  }
+  for (int t = lane; t < C::NV * C::LD; t += 64) s.M[t] = 0.0f;
+  WSYNC();
+  // composite inertia: item (b, c) sums cinert over the subtree of b
+  for (int t = lane; t < C::NB * 10; t += 64) {
+    int b = t / 10, c = t - 10 * b;
+    unsigned mask = b == 0 ? 0u : m.body_submask[b];
+    float acc = 0;
+    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.cinert[10 * k + c]; }
+    s.crb[t] = acc;
+  }
+  WSYNC();
+  if (lane < C::NV) {
+    int i = lane;
+    float f[6];
+    inert_mul(f, &s.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
+    unsigned mask = m.dof_ancmask[i];
+    while (mask) {
+      int j = __builtin_ctz(mask); mask &= mask - 1;
+      const float* cj = &s.cdof[6 * j];
+      float v = f[0] * cj[0] + f[1] * cj[1] + f[2] * cj[2] + f[3] * cj[3] + f[4] * cj[4] + f[5] * cj[5];
+      if (j == i) v += m.dof_armature[i];
+      s.M[i * C::LD + j] = v;
+      s.M[j * C::LD + i] = v;
+    }
+  }
+  WSYNC();
+}
+
+// =====================================================================================
+// in-register Cholesky, lane i = row i.  a[] holds row i (lower part used); on return a[] holds
+// row i of L, lt[] holds row i of L^T (column i of L) fetched through the LDS scratch T.
+// =====================================================================================
+template <class C>
+__device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV], float* T, int lane) {
+#pragma unroll
+  for (int k = 0; k < C::NV; ++k) {
+    float piv = rdlane(a[k], k);
+    piv = piv > 0.0f ? piv : RSR_MINVAL;
+    float d = sqrtf(piv), inv = 1.0f / d;
+    a[k] = (lane == k) ? d : a[k] * inv;        // column k of L (rows >= k meaningful)
+#pragma unroll
+    for (int j = k + 1; j < C::NV; ++j) {
+      float ljk = rdlane(a[k], j);
+      a[j] -= a[k] * ljk;                       // rows i >= j use it; others hold garbage never read
+    }
+  }
+  // transpose through LDS: T[k][i] = L[i][k]
+  if (lane < C::NV) {
+#pragma unroll
+    for (int k = 0; k < C::NV; ++k) T[k * C::LD + lane] = (k <= lane) ? a[k] : 0.0f;
+  }
+  WSYNC();
+  if (lane < C::NV) {
+#pragma unroll
+    for (int k = 0; k < C::NV; ++k) lt[k] = T[lane * C::LD + k];   // lt[k] = L[k][lane] (k >= lane)
+  }
+  WSYNC();
+}
+// solves L L^T x = b; lane i holds b_i in x and receives x_i
+template <class C>
+__device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float (&lt)[C::NV], float x, int lane) {
+#pragma unroll
+  for (int k = 0; k < C::NV; ++k) {          // forward: L y = b
+    float yk = rdlane(x, k) / rdlane(a[k], k);
+    x = (lane == k) ? yk : ((lane > k) ? x - a[k] * yk : x);
+  }
+#pragma unroll
+  for (int k = C::NV - 1; k >= 0; --k) {     // backward: L^T x = y
+    float xk = rdlane(x, k) / rdlane(a[k], k);
+    x = (lane == k) ? xk : ((lane < k) ? x - lt[k] * xk : x);
+  }
+  return x;
+}
+
+// broadcast a per-dof vector (lane i holds v_i) and multiply by a register-resident matrix row
+template <class C>
+__device__ __forceinline__ float row_dot(const float (&row)[C::NV], float v) {
+  float acc = 0;
+#pragma unroll
+  for (int j = 0; j < C::NV; ++j) acc += row[j] * rdlane(v, j);
+  return acc;
+}
+
+// =====================================================================================
+// stage 4: collision (lane = geom pair); penetrating contacts are compacted into the LDS list
+// =====================================================================================
+__device__ __forceinline__ void make_frame(V3 n, V3& a, V3& b, V3& c) {
+  float nn = sqrtf(dot(n, n));
+  a = nn > RSR_MINVAL ? n * (1.0f / nn) : v3(0, 0, 0);
+  b = (a.y > -0.5f && a.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
+  b = b - a * dot(a, b);
+  float bn = sqrtf(dot(b, b));
+  b = bn > RSR_MINVAL ? b * (1.0f / bn) : v3(0, 0, 0);
+  c = cross(a, b);
+}
+
+// choose <=4 of n masked 2-D points with approximately maximal area; see oracle manifold_points
+__device__ __forceinline__ void manifold_points(const float* x, const float* y, unsigned mask, int n, int* idx) {
+  const float NEG = -1e6f;
+  int a = 0, b = 0, c = 0, dd = 0;
+  float best = NEG * 2;
+  for (int i = 0; i < n; ++i) { float v = ((mask >> i) & 1) ? 0.0f : NEG; if (v > best) { best = v; a = i; } }
+  best = NEG * 4;
+  for (int i = 0; i < n; ++i) {
+    float dx = x[a] - x[i], dy = y[a] - y[i];
+    float v = dx * dx + dy * dy + (((mask >> i) & 1) ? 0.0f : NEG);
+    if (v > best) { best = v; b = i; }
+  }
+  float abx = -(y[a] - y[b]), aby = (x[a] - x[b]);
+  best = NEG * 4;
+  for (int i = 0; i < n; ++i) {
+    float v = fabsf((x[a] - x[i]) * abx + (y[a] - y[i]) * aby) + (((mask >> i) & 1) ? 0.0f : NEG);
+    if (v > best) { best = v; c = i; }
+  }
+  float sc = ((x[a] - x[c]) * abx + (y[a] - y[c]) * aby) > 0 ? 1.0f : -1.0f;
+  best = 0; dd = c;
+  for (int i = 0; i < n; ++i) {
+    float v = -sc * ((x[a] - x[i]) * abx + (y[a] - y[i]) * aby);
+    if (((mask >> i) & 1) && v > best) { best = v; dd = i; }
+  }
+  idx[0] = a; idx[1] = b; idx[2] = c; idx[3] = dd;
+}
+
+struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; };
+
+// scr: 48 floats of per-lane LDS scratch (two ping-pong polygons of <=8 (x, y, depth) points)
+__device__ void plane_box(V3 pp, const float* pm, V3 bp, const float* bm, V3 size, float* scr, CPts& out) {
+  V3 n = col(pm, 2), ax = col(pm, 0), ay = col(pm, 1);
+  out.n = n; out.cnt = 0;
+  float* sup = scr; float* vx = scr + 8; float* vy = scr + 16;
+  float smax = -1e30f;
+  for (int v = 0; v < 8; ++v) {
+    V3 loc = v3((v & 4) ? size.x : -size.x, (v & 2) ? size.y : -size.y, (v & 1) ? size.z : -size.z);
+    V3 w = mulv(bm, loc) + bp;
+    float sp = dot(pp - w, n);
+    sup[v] = sp; vx[v] = dot(w, ax); vy[v] = dot(w, ay);
+    smax = fmaxf(smax, sp);
+  }
+  if (!(smax > 0.0f)) return;
+  float thr = fmaxf(smax - 1e-3f, 0.0f);
+  unsigned mask = 0;
+  for (int v = 0; v < 8; ++v) if (sup[v] > thr) mask |= 1u << v;
+  int idx[4];
+  manifold_points(vx, vy, mask, 8, idx);
+  for (int i = 0; i < 4; ++i) {
+    bool dup = false;
+    for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
+    if (dup || !((mask >> idx[i]) & 1)) continue;
+    int v = idx[i];
+    float dist = -sup[v];
+    V3 loc = v3((v & 4) ? size.x : -size.x, (v & 2) ? size.y : -size.y, (v & 1) ? size.z : -size.z);
+    V3 w = mulv(bm, loc) + bp;
+    out.dist[out.cnt] = dist; out.pos[out.cnt] = w - n * (0.5f * dist); out.cnt++;
+  }
+}
+
+__device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, float* scr, CPts& out) {
+  out.cnt = 0;
+  float sa[3] = {sa_.x, sa_.y, sa_.z}, sb[3] = {sb_.x, sb_.y, sb_.z};
+  V3 dp = pb - pa;
+  float Cm[3][3], AC[3][3], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    V3 ai = col(Ra, i);
+    t[i] = dot(ai, dp);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { Cm[i][j] = dot(ai, col(Rb, j)); AC[i][j] = fabsf(Cm[i][j]) + 1e-6f; }
+  }
+  float best_face = -1e30f; int face_code = -1; bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float sv = fabsf(t[i]) - (sa[i] + sb[0] * AC[i][0] + sb[1] * AC[i][1] + sb[2] * AC[i][2]);
+    sep |= sv > 0.0f;
+    if (sv > best_face) { best_face = sv; face_code = i; }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float tb = t[0] * Cm[0][j] + t[1] * Cm[1][j] + t[2] * Cm[2][j];
+    float sv = fabsf(tb) - (sb[j] + sa[0] * AC[0][j] + sa[1] * AC[1][j] + sa[2] * AC[2][j]);
+    sep |= sv > 0.0f;
+    if (sv > best_face) { best_face = sv; face_code = 3 + j; }
+  }
+  if (sep) return;
+  float best_edge = -1e30f; int edge_i = -1, edge_j = -1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float l2 = 1.0f - Cm[i][j] * Cm[i][j];
+      if (l2 < 1e-6f) continue;
+      float ra = sa[i1] * AC[i2][j] + sa[i2] * AC[i1][j];
+      float rb = sb[j1] * AC[i][j2] + sb[j2] * AC[i][j1];
+      float tl = t[i2] * Cm[i1][j] - t[i1] * Cm[i2][j];
+      float sv = (fabsf(tl) - (ra + rb)) / sqrtf(l2);
+      sep |= sv > 0.0f;
+      if (sv > best_edge) { best_edge = sv; edge_i = i; edge_j = j; }
+    }
+  }
+  if (sep) return;
+  bool use_edge = (edge_i >= 0) && (best_edge > 0.95f * best_face + 1e-6f);
+  if (use_edge) {
+    V3 ai = col(Ra, edge_i), bj = col(Rb, edge_j);
+    V3 L = cross(ai, bj);
+    L = L * (1.0f / sqrtf(dot(L, L)));
+    if (dot(L, dp) < 0.0f) L = L * -1.0f;
+    V3 ea = pa, eb = pb;
+    for (int k = 0; k < 3; ++k) {
+      if (k != edge_i) { V3 ak = col(Ra, k); ea = ea + ak * ((dot(L, ak) > 0 ? 1.0f : -1.0f) * sa[k]); }
+      if (k != edge_j) { V3 bk = col(Rb, k); eb = eb + bk * ((dot(L, bk) > 0 ? -1.0f : 1.0f) * sb[k]); }
+    }
+    V3 r = eb - ea;
+    float uab = dot(ai, bj), q1 = dot(ai, r), q2 = -dot(bj, r), den = 1.0f - uab * uab;
+    float sp = clampf((q1 + uab * q2) / den, -sa[edge_i], sa[edge_i]);
+    float up = clampf((uab * q1 + q2) / den, -sb[edge_j], sb[edge_j]);
+    V3 qa = ea + ai * sp, qb = eb + bj * up;
+    float dist = dot(qb - qa, L);
+    if (!(dist < 0.0f)) return;
+    out.n = L; out.dist[0] = dist; out.pos[0] = (qa + qb) * 0.5f; out.cnt = 1;
+    return;
+  }
+  bool ref_is_a = face_code < 3;
+  int k = ref_is_a ? face_code : face_code - 3;
+  V3 pr = ref_is_a ? pa : pb, pq = ref_is_a ? pb : pa;
+  const float* Rr = ref_is_a ? Ra : Rb; const float* Rq = ref_is_a ? Rb : Ra;
+  const float* sr = ref_is_a ? sa : sb; const float* sq = ref_is_a ? sb : sa;
+  V3 nref = col(Rr, k);
+  if (dot(nref, pq - pr) < 0.0f) nref = nref * -1.0f;
+  int mq = 0; float bestd = -1.0f, dq[3];
+  for (int j = 0; j < 3; ++j) { dq[j] = dot(nref, col(Rq, j)); if (fabsf(dq[j]) > bestd) { bestd = fabsf(dq[j]); mq = j; } }
+  float sgn_q = dq[mq] > 0 ? -1.0f : 1.0f;
+  int uq = (mq + 1) % 3, vq = (mq + 2) % 3, ur = (k + 1) % 3, vr = (k + 2) % 3;
+  V3 axu = col(Rr, ur), axv = col(Rr, vr), o = pr + nref * sr[k];
+  V3 qm = col(Rq, mq), qu = col(Rq, uq), qv = col(Rq, vq);
+  // polygons in LDS scratch: buffer b, point i: scr[b*24 + i], +8, +16 for x, y, depth
+  const float su[4] = {1, -1, -1, 1}, sv4[4] = {1, 1, -1, -1};
+  for (int i = 0; i < 4; ++i) {
+    V3 w = pq + qm * (sgn_q * sq[mq]) + qu * (su[i] * sq[uq]) + qv * (sv4[i] * sq[vq]) - o;
+    scr[i] = dot(w, axu); scr[8 + i] = dot(w, axv); scr[16 + i] = -dot(w, nref);
+  }
+  int np = 4, cur = 0;
+  for (int side = 0; side < 4; ++side) {
+    float h = (side < 2) ? sr[ur] : sr[vr];
+    float sg = (side & 1) ? -1.0f : 1.0f;
+    float* P = scr + cur * 24; float* Qn = scr + (1 - cur) * 24;
+    const float* cx = (side < 2) ? P : P + 8;
+    int nn = 0;
+    for (int i = 0; i < np; ++i) {
+      int i2 = (i + 1 == np) ? 0 : i + 1;
+      float d1 = h - sg * cx[i], d2 = h - sg * cx[i2];
+      if (d1 >= 0.0f) { Qn[nn] = P[i]; Qn[8 + nn] = P[8 + i]; Qn[16 + nn] = P[16 + i]; nn++; }
+      if ((d1 >= 0.0f) != (d2 >= 0.0f)) {
+        float tt = d1 / (d1 - d2);
+        Qn[nn] = P[i] + tt * (P[i2] - P[i]);
+        Qn[8 + nn] = P[8 + i] + tt * (P[8 + i2] - P[8 + i]);
+        Qn[16 + nn] = P[16 + i] + tt * (P[16 + i2] - P[16 + i]);
+        nn++;
+      }
+    }
+    np = nn; cur = 1 - cur;
+    if (np == 0) return;
+  }
+  float* P = scr + cur * 24;
+  unsigned mask = 0;
+  for (int i = 0; i < np; ++i) if (P[16 + i] > 0.0f) mask |= 1u << i;
+  if (!mask) return;
+  int idx[4];
+  manifold_points(P, P + 8, mask, np, idx);
+  out.n = ref_is_a ? nref : nref * -1.0f;
+  for (int i = 0; i < 4; ++i) {
+    bool dup = false;
+    for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
+    if (dup || !((mask >> idx[i]) & 1)) continue;
+    float x = P[idx[i]], y = P[8 + idx[i]], dep = P[16 + idx[i]];
+    out.dist[out.cnt] = -dep;
+    out.pos[out.cnt] = o + axu * x + axv * y - nref * (0.5f * dep);
+    out.cnt++;
+  }
+}
+
+template <class C>
+__device__ void collision(const DModel& m, Smem<C>& s, int lane) {
+  CPts pts; pts.cnt = 0;
+  float* scr = &s.J[lane * 48];            // per-lane clip scratch aliases the (not yet built) Jacobian
+  static_assert(C::NEFC * C::LD >= 64 * 48, "clip scratch does not fit in the Jacobian tile");
+  float incl = 0.0f;
+  if (lane < C::NP) {
+    int p = lane, g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], kind = m.pair_kind[p];
+    incl = m.pair_margin[p] - m.pair_gap[p];
+    V3 p1 = ld3(&s.gpos[3 * g1]), p2 = ld3(&s.gpos[3 * g2]);
+    if (kind == PAIR_PLANE_BOX) plane_box(p1, &s.gmat[9 * g1], p2, &s.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), scr, pts);
+    else if (kind == PAIR_BOX_BOX)
+      box_box(p1, &s.gmat[9 * g1], ld3(&m.geom_size[3 * g1]), p2, &s.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), scr, pts);
+    else if (kind == PAIR_PLANE_SPHERE) {
+      V3 n = col(&s.gmat[9 * g1], 2);
+      float r = m.geom_size[3 * g2];
+      float dist = dot(p2 - p1, n) - r;
+      pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;
+    }
+  }
+  // keep penetrating contacts only (result-neutral culling), compact in pair order
+  int keep = 0;
+  for (int i = 0; i < pts.cnt; ++i) if (pts.dist[i] - incl < 0.0f) keep++;
+  int incl_scan = keep;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl_scan, o); if (lane >= o) incl_scan += v; }
+  int base = incl_scan - keep, total = __shfl(incl_scan, 63);
+  WSYNC();                                  // all lanes are done with the clip scratch
+  int w = base;
+  for (int i = 0; i < pts.cnt; ++i) {
+    if (!(pts.dist[i] - incl < 0.0f)) continue;
+    if (w < C::NCON) {
+      s.cdist[w] = pts.dist[i]; st3(&s.cpos[3 * w], pts.pos[i]); st3(&s.cnrm[3 * w], pts.n); s.cpair[w] = lane;
+    }
+    w++;
+  }
+  if (lane == 0) { s.ncon = total < C::NCON ? total : C::NCON; s.ncon_drop = total > C::NCON ? total - C::NCON : 0; }
+  WSYNC();
+}
+
+// =====================================================================================
+// stage 6: velocity-dependent terms (com_vel, passive, rne, actuation) -> qfrc_smooth (lane = dof)
+// =====================================================================================
+__device__ __forceinline__ void motion_cross(float* o, const float* u, const float* v) {
+  V3 ua = ld3(u), ul = ld3(u + 3), va = ld3(v), vl = ld3(v + 3);
+  st3(o, cross(ua, va));
+  st3(o + 3, cross(ul, va) + cross(ua, vl));
+}
+
+template <class C>
+__device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
+  // cvel[b] = sum over the dofs on b's chain of cdof*qvel
+  if (lane < C::NB) {
+    unsigned mask = m.body_dofmask[lane];
+    float v[6] = {0, 0, 0, 0, 0, 0};
+    while (mask) {
+      int i = __builtin_ctz(mask); mask &= mask - 1;
+      float qd = s.qvel[i];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s.cvel[6 * lane + c] = v[c];
+  }
+  // cdof_dot[i] = (velocity of the chain before dof i) x cdof[i]
+  if (lane < C::NV) {
+    unsigned mask = m.dof_velmask[lane];
+    int j = m.dof_jntid[lane];
+    bool free_trans = (m.jnt_type[j] == JNT_FREE) && (lane - m.jnt_dofadr[j] < 3);
+    float v[6] = {0, 0, 0, 0, 0, 0};
+    while (mask) {
+      int i = __builtin_ctz(mask); mask &= mask - 1;
+      float qd = s.qvel[i];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
+    }
+    float o[6];
+    motion_cross(o, v, &s.cdof[6 * lane]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s.cdofdot[6 * lane + c] = free_trans ? 0.0f : o[c];
+  }
+  WSYNC();
+  // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)
+  if (lane < C::NB) {
+    unsigned mask = m.body_dofmask[lane];
+    float a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    while (mask) {
+      int i = __builtin_ctz(mask); mask &= mask - 1;
+      float qd = s.qvel[i];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[c] += s.cdofdot[6 * i + c] * qd;
+    }
+    float f1[6], f2[6];
+    inert_mul(f1, &s.cinert[10 * lane], a);
+    inert_mul(f2, &s.cinert[10 * lane], &s.cvel[6 * lane]);
+    V3 va = ld3(&s.cvel[6 * lane]), vl = ld3(&s.cvel[6 * lane + 3]), fa = ld3(f2), fl = ld3(f2 + 3);
+    V3 ta = cross(va, fa) + cross(vl, fl), tl = cross(va, fl);
+    s.cfrc[6 * lane + 0] = f1[0] + ta.x; s.cfrc[6 * lane + 1] = f1[1] + ta.y; s.cfrc[6 * lane + 2] = f1[2] + ta.z;
+    s.cfrc[6 * lane + 3] = f1[3] + tl.x; s.cfrc[6 * lane + 4] = f1[4] + tl.y; s.cfrc[6 * lane + 5] = f1[5] + tl.z;
+  }
+  WSYNC();
+  for (int t = lane; t < C::NB * 6; t += 64) {
+    int b = t / 6, c = t - 6 * b;
+    unsigned mask = m.body_submask[b];
+    float acc = 0;
+    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.cfrc[6 * k + c]; }
+    s.cfrcsum[t] = acc;
+  }
+  WSYNC();
+  float smooth = 0.0f;
+  if (lane < C::NV) {
+    int i = lane, b = m.dof_bodyid[i];
+    float bias = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) bias += s.cdof[6 * i + c] * s.cfrcsum[6 * b + c];
+    float passive = -s.damp[i] * qvel_i;
+    // actuation: joint transmissions; lanes scan the (few) actuators for their dof
+    float act = 0;
+    for (int u = 0; u < C::NU; ++u) {
+      int j = m.actuator_trnid[u];
+      if (m.jnt_dofadr[j] != i) continue;
+      float gear = m.actuator_gear[u];
+      float length = s.qpos[m.jnt_qposadr[j]] * gear, velocity = qvel_i * gear;
+      float ctrl = s.ctrl[u];
+      if (m.actuator_ctrllimited[u]) ctrl = clampf(ctrl, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
+      float force = m.actuator_gainprm[3 * u] * ctrl + m.actuator_biasprm[3 * u] + m.actuator_biasprm[3 * u + 1] * length +
+                    m.actuator_biasprm[3 * u + 2] * velocity;
+      if (m.actuator_forcelimited[u]) force = clampf(force, m.actuator_forcerange[2 * u], m.actuator_forcerange[2 * u + 1]);
+      act += gear * force;
+    }
+    int j = m.dof_jntid[i];
+    if (m.jnt_actfrclimited[j]) act = clampf(act, m.jnt_actfrcrange[2 * j], m.jnt_actfrcrange[2 * j + 1]);
+    smooth = passive - bias + act;
+  }
+  (void)ctrl_u;
+  return smooth;
+}
+
+// =====================================================================================
+// stage 5: constraint rows.  Row order: equality, dof friction, active limits, contacts (6 pyramid
+// edges each).  J lives in LDS; the per-row scalars are returned in lane registers (row = lane + 64*c).
+// =====================================================================================
+struct RowRegs { float aref, D, R, floss; };   // floss < 0 marks "not a friction row"; D = 0 marks padding
+
+__device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const float* si, float pos, float& k, float& b, float& imp) {
+  float timeconst = sr0, dampratio = sr1;
+  if (!m.disable_refsafe) timeconst = fmaxf(timeconst, 2.0f * m.timestep);
+  float dmin = clampf(si[0], RSR_MINIMP, RSR_MAXIMP), dmax = clampf(si[1], RSR_MINIMP, RSR_MAXIMP);
+  float width = fmaxf(si[2], RSR_MINVAL), mid = clampf(si[3], RSR_MINIMP, RSR_MAXIMP), power = fmaxf(si[4], 1.0f);
+  k = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  b = 2.0f / (dmax * timeconst);
+  if (sr0 <= 0.0f) k = -sr0 / (dmax * dmax);
+  if (sr1 <= 0.0f) b = -sr1 / dmax;
+  float x = fabsf(pos) / width;
+  float ia = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
+  float ib = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  float y = x < mid ? ia : ib;
+  imp = clampf(dmin + y * (dmax - dmin), dmin, dmax);
+  if (x > 1.0f) imp = dmax;
+}
+
+template <class C>
+__device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK]) {
+  constexpr int LD = C::LD;
+  // active joint limits, compacted in joint order
+  int lim_active = 0;
+  if (lane < C::NL) {
+    int j = m.limit_jnts[lane];
+    float q = s.qpos[m.jnt_qposadr[j]];
+    float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
+    lim_active = (fminf(dmin, dmax) - m.jnt_margin[j]) < 0.0f;
+  }
+  unsigned long long bal = __ballot(lim_active);
+  int nl = __popcll(bal);
+  if (lim_active) s.lim_jnt[__popcll(bal & ((1ull << lane) - 1ull))] = m.limit_jnts[lane];
+  const int r_fric = C::NEQ, r_lim = C::NEQ + C::NF, r_con = r_lim + nl;
+  const int ncon = s.ncon;
+  const int nefc = r_con + 6 * ncon;
+  WSYNC();
+  // zero the sparse rows, then poke their entries
+  for (int t = lane; t < r_con * LD; t += 64) s.J[t] = 0.0f;
+  WSYNC();
+  if (lane < C::NEQ && m.eq_active0[lane]) {
+    int e = lane, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
+    float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
+    const float* dt = &m.eq_data[5 * e];
+    float deriv = dt[1] + dif * (2.0f * dt[2] + dif * (3.0f * dt[3] + dif * 4.0f * dt[4]));
+    if (j2 >= 0) s.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
+    s.J[e * LD + m.jnt_dofadr[j1]] = 1.0f;
+  }
+  if (lane < C::NF) s.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f;
+  if (lane < nl) {
+    int j = s.lim_jnt[lane];
+    float q = s.qpos[m.jnt_qposadr[j]];
+    float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
+    s.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
+  }
+  // contact rows: item (contact c, dof i) fills the six pyramid edges
+  for (int t = lane; t < ncon * C::NV; t += 64) {
+    int c = t / C::NV, i = t - c * C::NV;
+    int p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+    V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
+    make_frame(n, nn, t1, t2);
+    V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
+    float in1 = ((m.body_dofmask[b1] >> i) & 1) ? 1.0f : 0.0f, in2 = ((m.body_dofmask[b2] >> i) & 1) ? 1.0f : 0.0f;
+    V3 o1 = pos - ld3(&s.com[3 * m.body_rootid[b1]]), o2 = pos - ld3(&s.com[3 * m.body_rootid[b2]]);
+    V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
+    V3 jr = ang * (in2 - in1);
+    float dn = dot(nn, jp), d1 = dot(t1, jp), d2 = dot(t2, jp), dr = dot(nn, jr);
+    float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]), f1 = fmaxf(s.fric[3 * g1 + 1], s.fric[3 * g2 + 1]);
+    int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    if (pr1 != pr2) { int gw = pr1 > pr2 ? g1 : g2; f0 = s.fric[3 * gw]; f1 = s.fric[3 * gw + 1]; }
+    float* Jr = &s.J[(r_con + 6 * c) * LD + i];
+    Jr[0 * LD] = dn + f0 * d1; Jr[1 * LD] = dn - f0 * d1;
+    Jr[2 * LD] = dn + f0 * d2; Jr[3 * LD] = dn - f0 * d2;
+    Jr[4 * LD] = dn + f1 * dr; Jr[5 * LD] = dn - f1 * dr;
+  }
+  WSYNC();
+  // per-row reference acceleration, regulariser
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    int r = lane + 64 * ch;
+    RowRegs o{0.0f, 0.0f, 1.0f, -1.0f};
+    if (r < nefc) {
+      float pos = 0, invw = 0, sr0, sr1, fl = -1.0f; const float* si;
+      if (r < r_fric) {
+        int e = r, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
+        float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
+        const float* dt = &m.eq_data[5 * e];
+        float poly = dt[0] + dif * (dt[1] + dif * (dt[2] + dif * (dt[3] + dif * dt[4])));
+        pos = s.qpos[m.jnt_qposadr[j1]] - m.qpos0[m.jnt_qposadr[j1]] - poly;
+        invw = m.dof_invweight0[m.jnt_dofadr[j1]] + (j2 >= 0 ? m.dof_invweight0[m.jnt_dofadr[j2]] : 0.0f);
+        sr0 = m.eq_solref[2 * e]; sr1 = m.eq_solref[2 * e + 1]; si = &m.eq_solimp[5 * e];
+      } else if (r < r_lim) {
+        int i = m.fric_dofs[r - r_fric];
+        invw = m.dof_invweight0[i]; sr0 = m.dof_solref[2 * i]; sr1 = m.dof_solref[2 * i + 1]; si = &m.dof_solimp[5 * i];
+        fl = s.floss[i];
+      } else if (r < r_con) {
+        int j = s.lim_jnt[r - r_lim];
+        float q = s.qpos[m.jnt_qposadr[j]];
+        pos = fminf(q - m.jnt_range[2 * j], m.jnt_range[2 * j + 1] - q) - m.jnt_margin[j];
+        invw = m.dof_invweight0[m.jnt_dofadr[j]]; sr0 = m.jnt_solref[2 * j]; sr1 = m.jnt_solref[2 * j + 1]; si = &m.jnt_solimp[5 * j];
+      } else {
+        int c = (r - r_con) / 6, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+        pos = s.cdist[c] - (m.pair_margin[p] - m.pair_gap[p]);
+        float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]);
+        int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+        if (pr1 != pr2) f0 = s.fric[3 * (pr1 > pr2 ? g1 : g2)];
+        float tw = m.body_invweight0[2 * m.geom_bodyid[g1]] + m.body_invweight0[2 * m.geom_bodyid[g2]];
+        invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / m.impratio;
+        sr0 = m.pair_solref[2 * p]; sr1 = m.pair_solref[2 * p + 1]; si = &m.pair_solimp[5 * p];
+      }
+      float vel = 0;
+#pragma unroll
+      for (int i = 0; i < C::NV; ++i) vel += s.J[r * LD + i] * s.qvel[i];
+      float k, b, imp;
+      kbi(m, sr0, sr1, si, pos, k, b, imp);
+      float R = fmaxf(invw * (1.0f - imp) / imp, RSR_MINVAL);
+      o.R = R; o.D = 1.0f / R; o.aref = -b * vel - k * imp * pos; o.floss = fl;
+    }
+    rr[ch] = o;
+  }
+  if (lane == 0) s.nlim_act = nl;
+  return nefc;
+}
+
+}  // namespace rsr

@@ -1,0 +1,549 @@
+// rsr_mjx.hip -- fused env kernels (reset, step) and the C ABI of librsrmjx.so (include/rsr_mjx.h).
+// gfx950 only.  One wavefront per environment; see rsr_device.hpp for the execution model.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rsr_mjx.h"
+#include "rsr_solver.hpp"
+
+namespace rsr {
+
+// Airbot cube: nq 22, nv 20, nu 5, nbody 14, njnt 10, ngeom 23, nsite 1, npair 45, neq 1, nf 8, nl 8
+using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3>;
+
+// env_ids layout (rsr_mjx_amd/envs/config.py)
+enum { ID_CUBE = 0, ID_TARGET = 1, ID_SITE = 2, ID_BOXQ = 3, ID_SITEQ = 4, ID_FINGERQ = 5, ID_JOINTQ = 6 };
+
+// ---------------------------------------------------------------- threefry2x32 (jax.random default PRNG)
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x0 += x1; x1 = rotl32(x1, R[(g & 1) * 4 + k]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  o0 = x0; o1 = x1;
+}
+// bits[0..n) = threefry_2x32(key, iota(n)) in jax's split-halves layout; lane-parallel, result in LDS
+__device__ void random_bits(uint32_t k0, uint32_t k1, int n, uint32_t* bits, int lane) {
+  int half = (n + 1) / 2;
+  if (lane < half) {
+    uint32_t c1 = (half + lane < n) ? (uint32_t)(half + lane) : 0u, o0, o1;
+    threefry2x32(k0, k1, (uint32_t)lane, c1, o0, o1);
+    bits[lane] = o0;
+    if (half + lane < n) bits[half + lane] = o1;
+  }
+}
+__device__ __forceinline__ float uniform_from_bits(uint32_t b, float lo, float hi) {
+#pragma clang fp contract(off)   // jax does a separate multiply and add (HIP's __fmul_rn is a plain '*')
+  float u = __uint_as_float((b >> 9) | 0x3F800000u) - 1.0f;
+  float scale = hi - lo;
+  float prod = u * scale;
+  float v = prod + lo;
+  return fmaxf(lo, v);
+}
+
+// ---------------------------------------------------------------- record I/O
+template <class C>
+__device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, int e, int lane) {
+  for (int t = lane; t < C::NG * 3; t += 64) s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + t] : m.geom_friction[t];
+  if (lane < C::NB) s.mass[lane] = a.dr_body_mass ? a.dr_body_mass[(size_t)e * C::NB + lane] : m.body_mass[lane];
+  if (lane < C::NV) {
+    s.damp[lane] = a.dr_dof_damping ? a.dr_dof_damping[(size_t)e * C::NV + lane] : m.dof_damping[lane];
+    s.floss[lane] = a.dr_dof_frictionloss ? a.dr_dof_frictionloss[(size_t)e * C::NV + lane] : m.dof_frictionloss[lane];
+  }
+}
+
+// cube_env.py:215-229
+template <class C>
+__device__ void cube_obs(const DModel& m, const Smem<C>& s, const float* target_pos, const float* ncp, float* obs) {
+  const int cube = m.env_ids[ID_CUBE], site = m.env_ids[ID_SITE];
+  for (int i = 0; i < 6; ++i) obs[i] = s.qpos[m.env_ids[ID_JOINTQ + i]];
+  for (int i = 0; i < 3; ++i) {
+    float sp = s.spos[3 * site + i], cp = s.xpos[3 * cube + i], tp = target_pos[i];
+    obs[6 + i] = sp; obs[9 + i] = tp; obs[12 + i] = cp; obs[17 + i] = tp - cp; obs[20 + i] = cp - sp;
+  }
+  obs[15] = ncp[0]; obs[16] = ncp[1];
+}
+
+template <class C>
+__device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane, float warm, float time) {
+  for (int t = lane; t < C::NQ; t += 64) rec[L.qpos + t] = s.qpos[t];
+  if (lane < C::NV) { rec[L.qvel + lane] = s.qvel[lane]; rec[L.warm + lane] = warm; }
+  if (lane < C::NU) rec[L.ctrl + lane] = s.ctrl[lane];
+  if (lane == 0) rec[L.time] = time;
+  for (int t = lane; t < C::NB * 3; t += 64) rec[L.xpos + t] = s.xpos[t];
+  for (int t = lane; t < C::NS * 3; t += 64) rec[L.site_xpos + t] = s.spos[t];
+}
+
+// ---------------------------------------------------------------- reset kernel (cube_env.py:95-143 + wrappers)
+template <class C>
+__global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs a) {
+  __shared__ Smem<C> s;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const float* R = m.env_reset;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);         // PRNG scratch
+  load_overrides<C>(m, s, a, e, lane);
+  const uint32_t k0 = a.keys[2 * e], k1 = a.keys[2 * e + 1];
+  random_bits(k0, k1, 10, bits, lane);                        // rng, rng1..rng4 = split(rng, 5)
+  WSYNC();
+  uint32_t kk[5][2];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) { kk[r][0] = bits[2 * r]; kk[r][1] = bits[2 * r + 1]; }
+  WSYNC();
+  const float lo = -R[0], hi = R[0];
+  random_bits(kk[1][0], kk[1][1], C::NQ, bits, lane);
+  WSYNC();
+  if (lane < C::NQ) s.qpos[lane] = m.qpos0[lane] + uniform_from_bits(bits[lane], lo, hi);
+  WSYNC();
+  if (lane < 6) s.qpos[m.env_ids[ID_JOINTQ + lane]] += R[1 + lane];
+  if (lane == 6) s.qpos[m.env_ids[ID_FINGERQ]] = R[7];
+  random_bits(kk[2][0], kk[2][1], C::NV, bits, lane);
+  WSYNC();
+  if (lane < C::NV) s.qvel[lane] = uniform_from_bits(bits[lane], lo, hi);
+  WSYNC();
+  random_bits(kk[3][0], kk[3][1], C::NU, bits, lane);
+  WSYNC();
+  float ctrl_init = lane < C::NU ? R[8 + lane] + uniform_from_bits(bits[lane], lo, hi) : 0.0f;
+  WSYNC();
+  random_bits(kk[4][0], kk[4][1], 3, bits, lane);
+  WSYNC();
+  if (lane < 3) s.qpos[m.env_ids[ID_SITEQ] + lane] = uniform_from_bits(bits[lane], R[13 + lane], R[16 + lane]);
+  WSYNC();
+  random_bits(kk[0][0], kk[0][1], 3, bits, lane);
+  WSYNC();
+  if (lane < 3) s.qpos[m.env_ids[ID_BOXQ] + lane] = uniform_from_bits(bits[lane], R[19 + lane], R[22 + lane]);
+  if (lane < C::NU) s.ctrl[lane] = 0.0f;                      // pipeline_init runs forward with ctrl = 0
+  WSYNC();
+  float Mrow[C::NV], warm = 0.0f;
+  FwdOut<C> f;
+  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr);
+  WSYNC();
+  if (lane < C::NU) s.ctrl[lane] = ctrl_init;                 // data.replace(ctrl=joint_ctrl), no re-forward
+  WSYNC();
+  store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
+  const int cube = m.env_ids[ID_CUBE], tgt = m.env_ids[ID_TARGET], site = m.env_ids[ID_SITE];
+  if (lane == 0) {
+    float tp[3], ncp[2] = {R[25], R[26]}, obs[C::OBS];
+    for (int i = 0; i < 3; ++i) {
+      tp[i] = s.xpos[3 * tgt + i];
+      rec[L.target_pos + i] = tp[i];
+      rec[L.site_pos + i] = s.spos[3 * site + i];
+      rec[L.cube_pos + i] = s.xpos[3 * cube + i];
+    }
+    rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+    cube_obs<C>(m, s, tp, ncp, obs);
+    for (int i = 0; i < C::OBS; ++i) { rec[L.obs + i] = obs[i]; rec[L.f_obs + i] = obs[i]; }
+    rec[L.reward] = 0.0f; rec[L.done] = 0.0f;
+    for (int i = 0; i < C::NMET; ++i) rec[L.metrics + i] = 0.0f;
+    rec[L.steps] = 0.0f; rec[L.truncation] = 0.0f; rec[L.episode_done] = 0.0f;
+    for (int i = 0; i < 2 + C::NMET; ++i) rec[L.episode_metrics + i] = 0.0f;
+    int* st = reinterpret_cast<int*>(rec + L.stats);
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+  }
+  // AutoResetWrapper.reset: cache first_pipeline_state (same field order as the live block)
+  for (int t = lane; t < C::NQ; t += 64) rec[L.f_qpos + t] = s.qpos[t];
+  if (lane < C::NV) { rec[L.f_qvel + lane] = s.qvel[lane]; rec[L.f_warm + lane] = warm; }
+  if (lane < C::NU) rec[L.f_ctrl + lane] = s.ctrl[lane];
+  if (lane == 0) rec[L.f_time] = 0.0f;
+  for (int t = lane; t < C::NB * 3; t += 64) rec[L.f_xpos + t] = s.xpos[t];
+  for (int t = lane; t < C::NS * 3; t += 64) rec[L.f_site_xpos + t] = s.spos[t];
+}
+
+// ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
+template <class C>
+__global__ __launch_bounds__(64) void step_kernel(DModel m, Layout L, StepArgs a) {
+  __shared__ Smem<C> s;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
+  const int cube = m.env_ids[ID_CUBE], site = m.env_ids[ID_SITE];
+  // ---- load the record ----
+  for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
+  float warm = 0.0f;
+  if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
+  float time = rec[L.time];
+  load_overrides<C>(m, s, a, e, lane);
+  const float done_prev = rec[L.done];
+  float steps = rec[L.steps];
+  if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;     // AutoResetWrapper.step pre-step
+  float tp[3] = {rec[L.target_pos], rec[L.target_pos + 1], rec[L.target_pos + 2]};
+  float ncp_old[2] = {rec[L.new_cube_pos], rec[L.new_cube_pos + 1]};
+  // ---- prologue: ctrl shaping (cube_env.py:146-161); uses the stale xpos of the previous forward pass ----
+  if (lane < C::NU) {
+#pragma clang fp contract(off)   // env algebra is evaluated op by op, as the reference's JAX-CPU path does
+    float delta = m.env_action_scale[lane] * a.action[(size_t)e * C::NU + lane];
+    float act = rec[L.ctrl + lane] + delta;
+    if (lane == 3) act = -((1.57f + rec[L.qpos + m.env_ids[ID_JOINTQ + 1]]) + rec[L.qpos + m.env_ids[ID_JOINTQ + 2]]);
+    float delta0 = m.env_action_scale[0] * a.action[(size_t)e * C::NU];
+    float act0 = rec[L.ctrl] + delta0;
+    if (lane == 4) {
+      float dx = tp[0] - rec[L.xpos + 3 * cube], dy = tp[1] - rec[L.xpos + 3 * cube + 1];
+      float ang = atan2f(dy, dx + 0.00001f);
+      act = (-ang + act0) + 1.5708f;
+    }
+    s.ctrl[lane] = clampf(act, m.env_ctrl_lo[lane], m.env_ctrl_hi[lane]);
+  }
+  WSYNC();
+  // ---- n_frames x mjx.step ----
+  float Mrow[C::NV];
+  FwdOut<C> f;
+  for (int fr = 0; fr < m.n_frames; ++fr) {
+    float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
+    forward<C>(m, s, lane, Mrow, warm, f, dbg);
+    integrate<C>(m, s, lane, Mrow, f);
+    time += m.timestep;
+  }
+  // ---- epilogue: reward, done, obs, info (cube_env.py:164-213); derived data are from the last forward ----
+  float done = 0.0f;
+  float* obs_lds = s.T;                                     // staged so that auto-reset can override it
+  if (lane == 0) {
+#pragma clang fp contract(off)
+    const float* W = m.env_reward;
+    float cp[3] = {s.xpos[3 * cube], s.xpos[3 * cube + 1], s.xpos[3 * cube + 2]};
+    float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
+    float d0 = tp[0] - cp[0], d1 = tp[1] - cp[1], d2 = tp[2] - cp[2];
+    float btd = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    if (btd < 0.005f) btd = 0.0f;
+    float push = (1.0f / (1.0f + 3.0f * btd)) * W[0];
+    float site_z = sp[2] < 0.82f ? 1.0f : 0.0f;
+    float dx = tp[0] - cp[0], dy = tp[1] - cp[1];
+    float ang = atan2f(dy, dx + 0.00001f);
+    float dist = sqrtf(dx * dx + dy * dy) + 0.04f;
+    float y_ = dist * sinf(ang), x_ = dist * cosf(ang);
+    float ncp[2] = {dx - x_ + cp[0], dy - y_ + cp[1]};
+    float e0 = sp[0] - ncp_old[0], e1 = sp[1] - ncp_old[1];
+    float s2c = sqrtf(e0 * e0 + e1 * e1);
+    s2c = s2c < 0.042f ? 0.0f : s2c - 0.042f;
+    float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
+    if (btd < 0.005f) siet = W[1];
+    float health = W[2] * fabsf((sp[2] < W[3] ? 1.0f : 0.0f) - 1.0f);
+    float reward = clampf(push + siet + health + site_z, -100.0f, 100.0f);
+    done = cp[2] < 0.6f ? 1.0f : 0.0f;
+    cube_obs<C>(m, s, tp, ncp, obs_lds);
+    rec[L.metrics + 0] = push; rec[L.metrics + 2] = siet;
+    for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.cube_pos + i] = cp[i]; }
+    rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+    rec[L.reward] = reward;
+    // EpisodeWrapper.step (action_repeat = 1)
+    if (wrap_episode) {
+      steps += 1.0f;
+      bool over = steps >= (float)m.episode_length;
+      rec[L.truncation] = over ? 1.0f - done : 0.0f;
+      float prev_done = rec[L.episode_done];
+      float* em = rec + L.episode_metrics;
+      em[0] = (em[0] + reward) * (1.0f - prev_done);
+      em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
+      float met[3] = {push, rec[L.metrics + 1], siet};
+      for (int i = 0; i < C::NMET; ++i) em[2 + i] = (em[2 + i] + met[i]) * (1.0f - prev_done);
+      if (over) done = 1.0f;
+      rec[L.episode_done] = done;
+    }
+    rec[L.steps] = steps;
+    rec[L.done] = done;
+    int* st = reinterpret_cast<int*>(rec + L.stats);
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+  }
+  WSYNC();
+  done = rdlane(done, 0);
+  if (wrap_autoreset && done != 0.0f) {
+    // AutoResetWrapper.step post-step: the cached first state replaces the pipeline state and obs
+    for (int t = lane; t < L.persist_end; t += 64) rec[t] = rec[L.f_qpos + t];
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = rec[L.f_obs + t];
+  } else {
+    store_pipeline<C>(s, rec, L, lane, warm, time);
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = obs_lds[t];
+  }
+}
+
+}  // namespace rsr
+
+// =====================================================================================
+// host side: C ABI
+// =====================================================================================
+using rsr::DModel;
+using rsr::Layout;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(RSR_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct blob_entry { char name[40]; int32_t dtype, count, offset, reserved; };
+
+struct rsr_model {
+  std::vector<char> blob;
+  rsr_dims dims;
+  Layout layout;
+  const void* find(const char* name, int* count = nullptr) const {
+    const int32_t* h = reinterpret_cast<const int32_t*>(blob.data());
+    const blob_entry* e = reinterpret_cast<const blob_entry*>(blob.data() + 16);
+    for (int i = 0; i < h[2]; ++i)
+      if (std::strncmp(e[i].name, name, 40) == 0) { if (count) *count = e[i].count; return blob.data() + e[i].offset; }
+    if (count) *count = 0;
+    return nullptr;
+  }
+  ptrdiff_t offset_of(const char* name) const {
+    const void* p = find(name);
+    return p ? static_cast<const char*>(p) - blob.data() : -1;
+  }
+};
+
+struct rsr_batch {
+  const rsr_model* model;
+  int n, device;
+  float* state; bool owns_state;
+  char* dblob;
+  DModel dm;
+  const float *dr_fric, *dr_mass, *dr_damp, *dr_floss;
+  float* debug;
+  hipEvent_t ev0, ev1; bool timing; int launches;
+};
+
+static Layout make_layout(const rsr_dims& d) {
+  Layout L{};
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  L.qpos = take(d.nq); L.qvel = take(d.nv); L.ctrl = take(d.nu); L.warm = take(d.nv); L.time = take(1);
+  L.xpos = take(d.nbody * 3); L.site_xpos = take(d.nsite * 3);
+  L.persist_end = o;
+  L.f_qpos = take(d.nq); L.f_qvel = take(d.nv); L.f_ctrl = take(d.nu); L.f_warm = take(d.nv); L.f_time = take(1);
+  L.f_xpos = take(d.nbody * 3); L.f_site_xpos = take(d.nsite * 3);
+  L.obs = take(d.obs_dim); L.f_obs = take(d.obs_dim);
+  L.reward = take(1); L.done = take(1); L.metrics = take(d.nmetrics);
+  L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3);
+  L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
+  L.stats = take(4);
+  L.rec = (o + 15) & ~15;
+  return L;
+}
+
+extern "C" const char* rsr_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out) {
+  if (!blob || !out || nbytes < 32) return fail(RSR_ERR_ARG, "rsr_model_create: null or short blob");
+  const int32_t* h = static_cast<const int32_t*>(blob);
+  if (std::memcmp(blob, "RSRM", 4) != 0 || h[1] != 1 || (size_t)h[3] > nbytes) return fail(RSR_ERR_ARG, "rsr_model_create: not an RSRM v1 blob");
+  rsr_model* m = new rsr_model();
+  m->blob.assign(static_cast<const char*>(blob), static_cast<const char*>(blob) + nbytes);
+  const int* dims = static_cast<const int*>(m->find("dims"));
+  const int* ei = static_cast<const int*>(m->find("env_int"));
+  if (!dims || !ei) { delete m; return fail(RSR_ERR_ARG, "rsr_model_create: blob lacks dims/env_int"); }
+  rsr_dims& d = m->dims;
+  d.nq = dims[0]; d.nv = dims[1]; d.nu = dims[2]; d.nbody = dims[3]; d.njnt = dims[4]; d.ngeom = dims[5];
+  d.nsite = dims[6]; d.neq = dims[7]; d.npair = dims[8];
+  d.env_kind = ei[0]; d.n_frames = ei[1]; d.episode_length = ei[2]; d.obs_dim = ei[4]; d.nmetrics = ei[5];
+  using C = rsr::CubeDims;
+  const int* c2 = static_cast<const int*>(m->find("counts2"));
+  bool ok = d.env_kind == rsr::ENV_CUBE && d.nq == C::NQ && d.nv == C::NV && d.nu == C::NU && d.nbody == C::NB &&
+            d.njnt == C::NJ && d.ngeom == C::NG && d.nsite == C::NS && d.npair == C::NP && d.neq == C::NEQ && c2 &&
+            c2[0] == C::NF && c2[1] == C::NL && d.obs_dim == C::OBS && d.nmetrics == C::NMET;
+  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube)"); }
+  int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
+  for (int i = 0; i < npc; ++i) if (pc[i] != 4) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: only condim-4 contact pairs are built"); }
+  int nea = 0; const int* ea = static_cast<const int*>(m->find("eq_active0", &nea));
+  for (int i = 0; i < nea; ++i) if (!ea[i]) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: inactive equality constraints are not built"); }
+  if (static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_IMPLICITFAST &&
+      static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: integrator"); }
+  d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>);
+  m->layout = make_layout(d);
+  d.rec_floats = m->layout.rec;
+  *out = m;
+  return RSR_OK;
+}
+
+extern "C" int rsr_model_dims(const rsr_model* m, rsr_dims* out) {
+  if (!m || !out) return fail(RSR_ERR_ARG, "rsr_model_dims: null");
+  *out = m->dims;
+  return RSR_OK;
+}
+extern "C" void rsr_model_destroy(rsr_model* m) { delete m; }
+
+static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
+#define P(T, name) { ptrdiff_t o = m->offset_of(#name); if (o < 0) return fail(RSR_ERR_ARG, "blob lacks field " #name); dm.name = reinterpret_cast<const T*>(dbase + o); }
+  P(int, body_parentid) P(int, body_rootid) P(int, body_jntnum) P(int, body_jntadr) P(int, body_dofnum) P(int, body_dofadr)
+  P(float, body_pos) P(float, body_quat) P(float, body_ipos) P(float, body_iquat) P(float, body_mass) P(float, body_inertia) P(float, body_invweight0)
+  P(int, jnt_type) P(int, jnt_qposadr) P(int, jnt_dofadr) P(int, jnt_bodyid) P(int, jnt_limited) P(int, jnt_actfrclimited)
+  P(float, jnt_pos) P(float, jnt_axis) P(float, jnt_range) P(float, jnt_actfrcrange) P(float, jnt_solref) P(float, jnt_solimp) P(float, jnt_margin)
+  P(int, dof_bodyid) P(int, dof_jntid)
+  P(unsigned, dof_ancmask) P(unsigned, dof_velmask) P(unsigned, body_dofmask) P(unsigned, body_submask)
+  P(float, dof_armature) P(float, dof_damping) P(float, dof_frictionloss) P(float, dof_invweight0) P(float, dof_solref) P(float, dof_solimp)
+  P(int, geom_bodyid) P(int, geom_priority) P(float, geom_size) P(float, geom_pos) P(float, geom_quat) P(float, geom_friction)
+  P(int, site_bodyid) P(float, site_pos)
+  P(int, eq_obj1id) P(int, eq_obj2id) P(int, eq_active0) P(float, eq_data) P(float, eq_solref) P(float, eq_solimp)
+  P(int, actuator_trnid) P(int, actuator_ctrllimited) P(int, actuator_forcelimited)
+  P(float, actuator_gear) P(float, actuator_gainprm) P(float, actuator_biasprm) P(float, actuator_ctrlrange) P(float, actuator_forcerange)
+  P(int, pair_geom1) P(int, pair_geom2) P(int, pair_kind) P(int, pair_condim)
+  P(float, pair_solref) P(float, pair_solimp) P(float, pair_margin) P(float, pair_gap)
+  P(int, fric_dofs) P(int, limit_jnts) P(float, qpos0)
+  P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
+#undef P
+  auto F = [&](const char* n) { return static_cast<const float*>(m->find(n)); };
+  auto I = [&](const char* n) { return static_cast<const int*>(m->find(n)); };
+  dm.timestep = F("opt_timestep")[0];
+  for (int i = 0; i < 3; ++i) dm.gravity[i] = F("opt_gravity")[i];
+  dm.tolerance = F("opt_tolerance")[0]; dm.ls_tolerance = F("opt_ls_tolerance")[0]; dm.impratio = F("opt_impratio")[0];
+  dm.meaninertia = F("stat_meaninertia")[0];
+  dm.iterations = I("opt_iterations")[0]; dm.ls_iterations = I("opt_ls_iterations")[0]; dm.integrator = I("opt_integrator")[0];
+  dm.disable_eulerdamp = I("opt_disable_eulerdamp")[0]; dm.disable_refsafe = I("opt_disable_refsafe")[0];
+  dm.nfric = I("counts2")[0]; dm.nlimit = I("counts2")[1];
+  const int* ei = I("env_int");
+  dm.env_kind = ei[0]; dm.n_frames = ei[1]; dm.episode_length = ei[2]; dm.wrap_flags = ei[3];
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device, float* state, rsr_batch** out) {
+  if (!m || !out || num_envs <= 0) return fail(RSR_ERR_ARG, "rsr_batch_create: bad argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(RSR_ERR_HIP, std::string("rsr_batch_create: no HIP device (this library has no CPU path): hipGetDeviceCount -> ") +
+                                 hipGetErrorString(e) + ", count " + std::to_string(ndev));
+  if (hip_device < 0 || hip_device >= ndev) return fail(RSR_ERR_ARG, "rsr_batch_create: hip_device out of range");
+  HIPCHK(hipSetDevice(hip_device));
+  rsr_batch* b = new rsr_batch();
+  b->model = m; b->n = num_envs; b->device = hip_device;
+  b->dr_fric = b->dr_mass = b->dr_damp = b->dr_floss = nullptr; b->debug = nullptr;
+  b->timing = false; b->launches = 0; b->ev0 = b->ev1 = nullptr;
+  b->state = state; b->owns_state = false; b->dblob = nullptr;
+  if (!state) {
+    size_t bytes = (size_t)num_envs * m->layout.rec * sizeof(float);
+    if (hipMalloc(&b->state, bytes) != hipSuccess) { delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(state)"); }
+    b->owns_state = true;
+    (void)hipMemset(b->state, 0, bytes);
+  }
+  if (hipMalloc(&b->dblob, m->blob.size()) != hipSuccess) { if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(model)"); }
+  HIPCHK(hipMemcpy(b->dblob, m->blob.data(), m->blob.size(), hipMemcpyHostToDevice));
+  int rc = fill_dmodel(m, b->dblob, b->dm);
+  if (rc) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return rc; }
+  *out = b;
+  return RSR_OK;
+}
+
+extern "C" void rsr_batch_destroy(rsr_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->dblob) (void)hipFree(b->dblob);
+  if (b->owns_state && b->state) (void)hipFree(b->state);
+  delete b;
+}
+
+extern "C" int rsr_batch_set_dr(rsr_batch* b, const float* geom_friction, const float* body_mass, const float* dof_damping,
+                                const float* dof_frictionloss) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_dr: null batch");
+  b->dr_fric = geom_friction; b->dr_mass = body_mass; b->dr_damp = dof_damping; b->dr_floss = dof_frictionloss;
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_set_debug(rsr_batch* b, float* dev_buffer) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_debug: null batch");
+  b->debug = dev_buffer;
+  return RSR_OK;
+}
+
+static rsr::StepArgs make_args(rsr_batch* b) {
+  rsr::StepArgs a{};
+  a.state = b->state; a.n = b->n;
+  a.dr_geom_friction = b->dr_fric; a.dr_body_mass = b->dr_mass; a.dr_dof_damping = b->dr_damp; a.dr_dof_frictionloss = b->dr_floss;
+  a.debug = b->debug;
+  return a;
+}
+
+extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
+  if (!b || !keys) return fail(RSR_ERR_ARG, "rsr_reset: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  rsr::StepArgs a = make_args(b);
+  a.keys = keys;
+  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dm,
+                     b->model->layout, a);
+  HIPCHK(hipGetLastError());
+  return RSR_OK;
+}
+
+extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
+  if (!b || !action) return fail(RSR_ERR_ARG, "rsr_step: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  rsr::StepArgs a = make_args(b);
+  a.action = action;
+  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dm,
+                     b->model->layout, a);
+  HIPCHK(hipGetLastError());
+  if (b->timing) b->launches++;
+  return RSR_OK;
+}
+
+extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shape[2], int64_t stride[2]) {
+  if (!b || !dev_ptr || !shape || !stride) return fail(RSR_ERR_ARG, "rsr_view: null argument");
+  const Layout& L = b->model->layout;
+  const rsr_dims& d = b->model->dims;
+  int off = -1, w = 0;
+  switch (field_id) {
+    case RSR_F_QPOS: off = L.qpos; w = d.nq; break;
+    case RSR_F_QVEL: off = L.qvel; w = d.nv; break;
+    case RSR_F_CTRL: off = L.ctrl; w = d.nu; break;
+    case RSR_F_QACC_WARMSTART: off = L.warm; w = d.nv; break;
+    case RSR_F_TIME: off = L.time; w = 1; break;
+    case RSR_F_XPOS: off = L.xpos; w = d.nbody * 3; break;
+    case RSR_F_SITE_XPOS: off = L.site_xpos; w = d.nsite * 3; break;
+    case RSR_F_OBS: off = L.obs; w = d.obs_dim; break;
+    case RSR_F_REWARD: off = L.reward; w = 1; break;
+    case RSR_F_DONE: off = L.done; w = 1; break;
+    case RSR_F_METRICS: off = L.metrics; w = d.nmetrics; break;
+    case RSR_F_INFO_TARGET_POS: off = L.target_pos; w = 3; break;
+    case RSR_F_INFO_NEW_CUBE_POS: off = L.new_cube_pos; w = 2; break;
+    case RSR_F_INFO_SITE_POS: off = L.site_pos; w = 3; break;
+    case RSR_F_INFO_CUBE_POS: off = L.cube_pos; w = 3; break;
+    case RSR_F_INFO_STEPS: off = L.steps; w = 1; break;
+    case RSR_F_INFO_TRUNCATION: off = L.truncation; w = 1; break;
+    case RSR_F_INFO_EPISODE_DONE: off = L.episode_done; w = 1; break;
+    case RSR_F_INFO_EPISODE_METRICS: off = L.episode_metrics; w = 2 + d.nmetrics; break;
+    case RSR_F_FIRST_QPOS: off = L.f_qpos; w = d.nq; break;
+    case RSR_F_FIRST_QVEL: off = L.f_qvel; w = d.nv; break;
+    case RSR_F_FIRST_CTRL: off = L.f_ctrl; w = d.nu; break;
+    case RSR_F_FIRST_WARMSTART: off = L.f_warm; w = d.nv; break;
+    case RSR_F_FIRST_TIME: off = L.f_time; w = 1; break;
+    case RSR_F_FIRST_XPOS: off = L.f_xpos; w = d.nbody * 3; break;
+    case RSR_F_FIRST_SITE_XPOS: off = L.f_site_xpos; w = d.nsite * 3; break;
+    case RSR_F_FIRST_OBS: off = L.f_obs; w = d.obs_dim; break;
+    case RSR_F_STATS: off = L.stats; w = 4; break;
+    default: return fail(RSR_ERR_ARG, "rsr_view: unknown field id");
+  }
+  *dev_ptr = b->state + off;
+  shape[0] = b->n; shape[1] = w;
+  stride[0] = L.rec; stride[1] = 1;
+  return RSR_OK;
+}
+
+extern "C" int rsr_timing_begin(rsr_batch* b, void* hip_stream) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_timing_begin: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->ev0) { HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1)); }
+  b->launches = 0; b->timing = true;
+  HIPCHK(hipEventRecord(b->ev0, static_cast<hipStream_t>(hip_stream)));
+  return RSR_OK;
+}
+
+extern "C" int rsr_timing_end(rsr_batch* b, void* hip_stream, float* total_ms, int* launches) {
+  if (!b || !b->timing || !total_ms || !launches) return fail(RSR_ERR_ARG, "rsr_timing_end: bad argument / timing not begun");
+  HIPCHK(hipEventRecord(b->ev1, static_cast<hipStream_t>(hip_stream)));
+  HIPCHK(hipEventSynchronize(b->ev1));
+  HIPCHK(hipEventElapsedTime(total_ms, b->ev0, b->ev1));
+  *launches = b->launches;
+  b->timing = false;
+  return RSR_OK;
+}

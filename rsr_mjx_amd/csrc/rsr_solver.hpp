@@ -1,0 +1,348 @@
+// rsr_solver.hpp -- Newton constraint solver, integrator and forward pass for one env / one wavefront.
+// Restates MJX solver.solve / _linesearch / _update_constraint / _update_gradient
+// with per-row scalars in lane registers, J in LDS, the Hessian assembled as 2x2 blocks (one block per
+// lane) and factored by the in-register Cholesky of rsr_device.hpp.
+#pragma once
+#include "rsr_device.hpp"
+
+namespace rsr {
+
+// per-dof vectors live in registers of lane i (i < NV); lanes >= NV carry zeros
+template <class C>
+struct DofRegs { float qacc, Ma, grad, search, mv, qfc; };
+
+// J * v for the rows owned by this lane (v: per-dof vector, lane i holds v_i)
+template <class C>
+__device__ __forceinline__ void jdot(const Smem<C>& s, int lane, int nefc, float v, float (&out)[C::NCHUNK]) {
+  float vb[C::NV];
+#pragma unroll
+  for (int i = 0; i < C::NV; ++i) vb[i] = rdlane(v, i);
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    int r = lane + 64 * ch;
+    float acc = 0;
+    if (r < nefc) {
+#pragma unroll
+      for (int i = 0; i < C::NV; ++i) acc += s.J[r * C::LD + i] * vb[i];
+    }
+    out[ch] = acc;
+  }
+}
+
+// row classification by index
+template <class C>
+__device__ __forceinline__ int row_kind(int r) { return r < C::NEQ ? 0 : (r < C::NEQ + C::NF ? 1 : 2); }
+
+// cost of the constraint rows at Jaref; optionally emits force and Hessian weight per row
+template <class C>
+__device__ __forceinline__ float rows_cost(int lane, const float (&jaref)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK],
+                                           float (&force)[C::NCHUNK], float (&hw)[C::NCHUNK]) {
+  float cost = 0;
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    int r = lane + 64 * ch, kind = row_kind<C>(r);
+    float x = jaref[ch], D = rr[ch].D, f = 0, w = 0;
+    bool act;
+    if (kind == 0) act = true;
+    else if (kind == 1) {
+      float fl = rr[ch].floss, rf = rr[ch].R * fl;
+      if (x <= -rf) { act = false; f = fl; cost += fl * (-0.5f * rf - x); }
+      else if (x >= rf) { act = false; f = -fl; cost += fl * (-0.5f * rf + x); }
+      else act = true;
+    } else act = x < 0.0f;
+    if (act) { f = -D * x; cost += 0.5f * D * x * x; w = D; }
+    force[ch] = f; hw[ch] = w;
+  }
+  return wave_sum(cost);
+}
+
+struct LSPoint { float alpha, cost, d0, d1; };
+
+template <class C>
+__device__ __forceinline__ LSPoint ls_point(int lane, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
+                                            const RowRegs (&rr)[C::NCHUNK], float g0, float g1, float g2) {
+  float q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    int r = lane + 64 * ch, kind = row_kind<C>(r);
+    float ja = jaref[ch], v = jv[ch], D = rr[ch].D;
+    float x = ja + alpha * v;
+    float a0 = 0.5f * ja * ja * D, a1 = v * ja * D, a2 = 0.5f * v * v * D;
+    if (kind == 1) {
+      float f = rr[ch].floss, rf = rr[ch].R * f;
+      if (x <= -rf) { a0 = f * (-0.5f * rf - ja); a1 = -f * v; a2 = 0; }
+      else if (x >= rf) { a0 = f * (-0.5f * rf + ja); a1 = f * v; a2 = 0; }
+    } else if (kind == 2 && !(x < 0.0f)) { a0 = a1 = a2 = 0; }
+    q0 += a0; q1 += a1; q2 += a2;
+  }
+  q0 = wave_sum(q0) + g0; q1 = wave_sum(q1) + g1; q2 = wave_sum(q2) + g2;
+  LSPoint p;
+  p.alpha = alpha;
+  p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+  p.d0 = 2.0f * alpha * q2 + q1;
+  p.d1 = 2.0f * q2 + (q2 == 0.0f ? RSR_MINVAL : 0.0f);
+  return p;
+}
+
+// qfrc_constraint = J^T force ; rows with zero force are skipped (wave-uniform loop over a ballot)
+template <class C>
+__device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, const float (&force)[C::NCHUNK]) {
+  WSYNC();
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = force[ch]; }
+  WSYNC();
+  float acc = 0;
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    unsigned long long mask = __ballot(force[ch] != 0.0f && (lane + 64 * ch) < nefc);
+    while (mask) {
+      int r = __builtin_ctzll(mask) + 64 * ch; mask &= mask - 1;
+      if (lane < C::NV) acc += s.J[r * C::LD + lane] * s.rw[r];
+    }
+  }
+  return acc;
+}
+
+// H = M + J^T diag(hw) J as 2x2 blocks (lane = block of the lower triangle), then factor.
+template <class C>
+__device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, const float (&hw)[C::NCHUNK],
+                                               float (&a)[C::NV], float (&lt)[C::NV]) {
+  constexpr int NBLK = (C::NV + 1) / 2;
+  static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
+  static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
+  WSYNC();
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = hw[ch]; }
+  WSYNC();
+  int bi = 0;
+  while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
+  int bj = lane - bi * (bi + 1) / 2;
+  bool blk = bi < NBLK;
+  int i0 = blk ? 2 * bi : 0, j0 = blk ? 2 * bj : 0;
+  float h00 = s.M[i0 * C::LD + j0], h01 = s.M[i0 * C::LD + j0 + 1];
+  float h10 = s.M[(i0 + 1) * C::LD + j0], h11 = s.M[(i0 + 1) * C::LD + j0 + 1];
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    unsigned long long mask = __ballot(hw[ch] != 0.0f && (lane + 64 * ch) < nefc);
+    while (mask) {
+      int r = __builtin_ctzll(mask) + 64 * ch; mask &= mask - 1;
+      const float* Jr = &s.J[r * C::LD];
+      float w = s.rw[r];
+      float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
+      h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
+    }
+  }
+  if (blk) {
+    s.T[i0 * C::LD + j0] = h00; s.T[(i0 + 1) * C::LD + j0] = h10; s.T[(i0 + 1) * C::LD + j0 + 1] = h11;
+    if (bi != bj) s.T[i0 * C::LD + j0 + 1] = h01;     // diagonal blocks: (i0, i0+1) is upper, never read
+  }
+  WSYNC();
+#pragma unroll
+  for (int j = 0; j < C::NV; ++j) a[j] = (lane < C::NV && j <= lane) ? s.T[lane * C::LD + j] : 0.0f;
+  WSYNC();
+  chol_factor<C>(a, lt, s.T, lane);
+}
+
+struct SolveStats { int niter, ls_total; };
+
+// Newton solve.  In: Mrow (row i of M in lane i), fs = qfrc_smooth_i, a0 = qacc_smooth_i, warm_i.
+// Out: qacc_i, qfrc_constraint_i.
+template <class C>
+__device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const RowRegs (&rr)[C::NCHUNK],
+                      const float (&Mrow)[C::NV], float fs, float a0, float warm, float& qacc_out, float& qfc_out,
+                      SolveStats& st) {
+  const bool dofl = lane < C::NV;
+  float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
+  float a[C::NV], lt[C::NV];
+  // --- warm start: the cheaper of qacc_warmstart and qacc_smooth (cost only) ---
+  float Ma_w = dofl ? row_dot<C>(Mrow, warm) : 0.0f;
+  jdot<C>(s, lane, nefc, warm, tmp);
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
+  float cost_w = rows_cost<C>(lane, jaref, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_w - fs) * (warm - a0) : 0.0f);
+  float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
+  float jar_s[C::NCHUNK];
+  jdot<C>(s, lane, nefc, a0, tmp);
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
+  float cost_s = rows_cost<C>(lane, jar_s, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_s - fs) * (a0 - a0) : 0.0f);
+  const bool use_warm = cost_w < cost_s;
+  float qacc = use_warm ? warm : a0, Ma = use_warm ? Ma_w : Ma_s;
+  if (!use_warm) {
+#pragma unroll
+    for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = jar_s[ch];
+  }
+  // --- context at the start point ---
+  float gauss, cost, prev_cost = INFINITY;
+  float rc = rows_cost<C>(lane, jaref, rr, force, hw);
+  gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
+  cost = rc + gauss;
+  float qfc = jt_force<C>(s, lane, nefc, force);
+  float grad = dofl ? Ma - fs - qfc : 0.0f;
+  hessian_factor<C>(s, lane, nefc, hw, a, lt);
+  float search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+  const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
+  int iter = 0, ls_total = 0;
+  while (true) {
+    bool done;
+    if (m.iterations != 1) {
+      float gn = sqrtf(wave_sum(grad * grad));
+      done = iter >= m.iterations;
+      done |= scale * (prev_cost - cost) < m.tolerance;
+      done |= scale * gn < m.tolerance;
+    } else done = iter >= 1;
+    if (uniform_i(done)) break;
+    // ---------------- line search ----------------
+    float snorm = sqrtf(wave_sum(search * search));
+    float gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * (float)(C::NV > 1 ? C::NV : 1);
+    float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
+    jdot<C>(s, lane, nefc, search, jv);
+    float g1 = wave_sum(search * Ma) - wave_sum(search * fs);
+    float g2 = 0.5f * wave_sum(search * mv);
+    LSPoint p0 = ls_point<C>(lane, 0.0f, jaref, jv, rr, gauss, g1, g2);
+    LSPoint lo = ls_point<C>(lane, p0.alpha - p0.d0 / p0.d1, jaref, jv, rr, gauss, g1, g2), hi;
+    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    bool swap = true; int it = 0;
+    while (true) {
+      bool ldone = it >= m.ls_iterations;
+      ldone |= !swap;
+      ldone |= (lo.d0 < 0.0f) && (lo.d0 > -gtol);
+      ldone |= (hi.d0 > 0.0f) && (hi.d0 < gtol);
+      if (uniform_i(ldone)) break;
+      LSPoint lo_next = ls_point<C>(lane, lo.alpha - lo.d0 / lo.d1, jaref, jv, rr, gauss, g1, g2);
+      LSPoint hi_next = ls_point<C>(lane, hi.alpha - hi.d0 / hi.d1, jaref, jv, rr, gauss, g1, g2);
+      LSPoint mid = ls_point<C>(lane, 0.5f * (lo.alpha + hi.alpha), jaref, jv, rr, gauss, g1, g2);
+      bool s1 = (lo.d0 > 0.0f) || (lo.d0 < lo_next.d0);
+      if (s1) lo = lo_next;
+      bool s2 = (mid.d0 < 0.0f) && (lo.d0 < mid.d0);
+      if (s2) lo = mid;
+      bool s3 = (hi.d0 < 0.0f) || (hi.d0 > hi_next.d0);
+      if (s3) hi = hi_next;
+      bool s4 = (mid.d0 > 0.0f) && (hi.d0 > mid.d0);
+      if (s4) hi = mid;
+      swap = s1 | s2 | s3 | s4;
+      ++it;
+    }
+    ls_total += it;
+    bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+    float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    if (improved) {
+      qacc += alpha * search; Ma += alpha * mv;
+#pragma unroll
+      for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] += alpha * jv[ch];
+    }
+    // ---------------- update constraint + gradient ----------------
+    rc = rows_cost<C>(lane, jaref, rr, force, hw);
+    gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
+    prev_cost = cost; cost = rc + gauss;
+    qfc = jt_force<C>(s, lane, nefc, force);
+    grad = dofl ? Ma - fs - qfc : 0.0f;
+    hessian_factor<C>(s, lane, nefc, hw, a, lt);
+    search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+    ++iter;
+  }
+  st.niter = iter; st.ls_total = ls_total;
+  qacc_out = qacc; qfc_out = qfc;
+}
+
+// per-lane registers that survive one forward pass
+template <class C>
+struct FwdOut { float qacc, qfc, fsmooth; int nefc; SolveStats st; };
+
+// MJX forward(): position -> collision -> constraint rows -> velocity/actuation -> solve.
+// warm_i is read and replaced by the solver's qacc (qacc_warmstart <- qacc).
+template <class C>
+__device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
+                        float* dbg) {
+  kinematics<C>(m, s, lane);
+  com_crb_mass<C>(m, s, lane);
+#pragma unroll
+  for (int j = 0; j < C::NV; ++j) Mrow[j] = lane < C::NV ? s.M[lane * C::LD + j] : 0.0f;
+  collision<C>(m, s, lane);
+  RowRegs rr[C::NCHUNK];
+  int nefc = make_constraint<C>(m, s, lane, rr);
+  float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
+  float fs = smooth_forces<C>(m, s, lane, qvel_i, 0.0f);
+  // qacc_smooth = M^-1 qfrc_smooth
+  float a[C::NV], lt[C::NV];
+#pragma unroll
+  for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] : 0.0f;
+  chol_factor<C>(a, lt, s.T, lane);
+  float a0 = lane < C::NV ? chol_solve<C>(a, lt, fs, lane) : 0.0f;
+  out.fsmooth = fs; out.nefc = nefc;
+  solve<C>(m, s, lane, nefc, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st);
+  warm = out.qacc;
+  if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
+    if (lane == 0) {
+      dbg[0] = (float)nefc; dbg[1] = (float)C::NEQ; dbg[2] = (float)C::NF; dbg[3] = (float)s.ncon;
+      dbg[4] = (float)out.st.niter; dbg[5] = (float)out.st.ls_total; dbg[6] = (float)s.nlim_act; dbg[7] = (float)s.ncon_drop;
+    }
+    for (int t = lane; t < C::NB * 3; t += 64) dbg[16 + t] = s.xpos[t];
+    for (int t = lane; t < C::NB * 4; t += 64) dbg[64 + t] = s.xquat[t];
+    for (int t = lane; t < C::NV * C::NV; t += 64) dbg[128 + t] = s.M[(t / C::NV) * C::LD + (t % C::NV)];
+    if (lane < C::NV) {
+      dbg[736 + lane] = fs; dbg[768 + lane] = a0; dbg[800 + lane] = out.qacc; dbg[832 + lane] = out.qfc;
+    }
+    for (int t = lane; t < s.ncon; t += 64) {
+      float* c = &dbg[864 + 8 * t];
+      c[0] = s.cdist[t]; c[1] = s.cpos[3 * t]; c[2] = s.cpos[3 * t + 1]; c[3] = s.cpos[3 * t + 2];
+      c[4] = s.cnrm[3 * t]; c[5] = s.cnrm[3 * t + 1]; c[6] = s.cnrm[3 * t + 2]; c[7] = (float)s.cpair[t];
+    }
+#pragma unroll
+    for (int ch = 0; ch < C::NCHUNK; ++ch) {
+      int r = lane + 64 * ch;
+      if (r < nefc && r < 256) { dbg[1152 + r] = rr[ch].aref; dbg[1408 + r] = rr[ch].D; }
+    }
+    for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) dbg[2048 + t] = s.J[(t / C::NV) * C::LD + (t % C::NV)];
+    for (int t = lane; t < C::NG * 3; t += 64) dbg[6400 + t] = s.gpos[t];
+    for (int t = lane; t < C::NV * 6; t += 64) dbg[6528 + t] = s.cdof[t];
+    for (int t = lane; t < C::NB * 10; t += 64) dbg[6656 + t] = s.cinert[t];
+    for (int t = lane; t < C::NB * 3; t += 64) dbg[6800 + t] = s.com[t];
+    for (int t = lane; t < C::NB * 6; t += 64) dbg[6848 + t] = s.cvel[t];
+    for (int t = lane; t < C::NV * 6; t += 64) dbg[6944 + t] = s.cdofdot[t];
+  }
+}
+
+// integrate one substep after forward(): implicitfast / Euler, then _advance
+template <class C>
+__device__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f) {
+  float qacc = f.qacc;
+  bool implicit = m.integrator == INT_IMPLICITFAST;
+  if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
+    float dm = lane < C::NV ? fabsf(s.damp[lane]) : 0.0f;
+    implicit = uniform_i(__ballot(dm != 0.0f) != 0ull);
+  }
+  if (implicit) {
+    float a[C::NV], lt[C::NV];
+    float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] + (j == lane ? dd : 0.0f) : 0.0f;
+    chol_factor<C>(a, lt, s.T, lane);
+    qacc = lane < C::NV ? chol_solve<C>(a, lt, f.fsmooth + f.qfc, lane) : 0.0f;
+  }
+  WSYNC();
+  if (lane < C::NV) s.qvel[lane] += qacc * m.timestep;
+  WSYNC();
+  if (lane < C::NJ) {
+    int j = lane, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    float dt = m.timestep;
+    if (m.jnt_type[j] == JNT_FREE) {
+      s.qpos[qa] += dt * s.qvel[da]; s.qpos[qa + 1] += dt * s.qvel[da + 1]; s.qpos[qa + 2] += dt * s.qvel[da + 2];
+      V3 w = ld3(&s.qvel[da + 3]);
+      float n = sqrtf(dot(w, w));
+      V3 ax = n > RSR_MINVAL ? w * (1.0f / n) : v3(0, 0, 0);
+      float sn, cs;
+      sincosf(0.5f * dt * n, &sn, &cs);
+      Q4 q = qmul(ld4(&s.qpos[qa + 3]), Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
+      float qn = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+      if (qn < RSR_MINVAL) q = Q4{1, 0, 0, 0};
+      else { float inv = 1.0f / qn; q = Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv}; }
+      st4(&s.qpos[qa + 3], q);
+    } else {
+      s.qpos[qa] += dt * s.qvel[da];
+    }
+  }
+  WSYNC();
+}
+
+}  // namespace rsr

@@ -79,4 +79,57 @@ def model_fields(m: CompiledModel) -> Dict[str, np.ndarray]:
         f[k] = np.asarray(v)
     f["dims"] = np.array([m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.nsite,
                           int(m.arrays["eq_obj1id"].shape[0]), m.npair], dtype=np.int32)
+    f.update(topology_tables(m))
     return f
+
+
+def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
+    """Bitmask tables that let the kernel replace the tree recursions of the reference's
+    scan.body_tree passes by independent per-lane loops (all models here have nv, nbody <= 32).
+
+      dof_ancmask[i]  : dofs j that are ancestors of dof i, i included        (mass matrix, Jacobians)
+      dof_velmask[i]  : dofs whose cdof*qvel make up the body velocity seen by cdof_dot[i]
+                        (all strict ancestors for hinge/slide; for the rotational dofs of a free joint
+                        only that joint's three translational dofs; empty for free translations)
+      body_dofmask[b] : dofs on the chain from the root to body b, b's own included
+      body_submask[b] : bodies in the subtree of b, b included
+      fric_dofs       : dofs with frictionloss > 0 (constraint rows exist for them)
+      limit_jnts      : limited hinge/slide joints
+    """
+    A = m.arrays
+    nv, nb = m.nv, m.nbody
+    if nv > 32 or nb > 32:
+        raise ValueError("topology bitmasks need nv, nbody <= 32")
+    anc = np.zeros(nv, dtype=np.int64)
+    for i in range(nv):
+        j = i
+        while j >= 0:
+            anc[i] |= 1 << j
+            j = int(A["dof_parentid"][j])
+    vel = np.zeros(nv, dtype=np.int64)
+    for i in range(nv):
+        jid = int(A["dof_jntid"][i])
+        da = int(A["jnt_dofadr"][jid])
+        if A["jnt_type"][jid] == 0:           # free
+            vel[i] = 0 if i < da + 3 else (0b111 << da)
+        else:
+            vel[i] = anc[i] & ~(1 << i)
+    bdof = np.zeros(nb, dtype=np.int64)
+    for b in range(1, nb):
+        k = b
+        while k > 0 and A["body_dofnum"][k] == 0:
+            k = int(A["body_parentid"][k])
+        if k > 0:
+            last = int(A["body_dofadr"][k] + A["body_dofnum"][k] - 1)
+            bdof[b] = anc[last]
+    sub = np.zeros(nb, dtype=np.int64)
+    for b in range(nb - 1, -1, -1):
+        sub[b] |= 1 << b
+        if b > 0:
+            sub[int(A["body_parentid"][b])] |= sub[b]
+    fric = np.array([i for i in range(nv) if A["dof_frictionloss"][i] > 0], dtype=np.int32)
+    lim = np.array([j for j in range(m.njnt) if A["jnt_limited"][j] and A["jnt_type"][j] in (2, 3)], dtype=np.int32)
+    as_i32 = lambda a: a.astype(np.uint32).view(np.int32)
+    return dict(dof_ancmask=as_i32(anc), dof_velmask=as_i32(vel), body_dofmask=as_i32(bdof),
+                body_submask=as_i32(sub), fric_dofs=fric, limit_jnts=lim,
+                counts2=np.array([len(fric), len(lim)], dtype=np.int32))

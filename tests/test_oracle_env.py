@@ -1,0 +1,206 @@
+"""Env algebra and wrapper semantics of the oracle against the reference source text
+(ppo_train/airbot_training/cube_env.py) restated independently in numpy, hand-computed cases,
+and the committed regression fixture (BASELINE.json configs[0])."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_blob
+from rsr_mjx_amd import prng
+
+GOLD = os.path.join(ROOT, "tests", "golden", "cube_n4_200.npz")
+
+
+def _np_reward_obs(pre, post, W=(6.0, 3.0, 1.0, 0.778)):
+    """cube_env.py:164-229 in numpy float32, written from the source text (not from the oracle)."""
+    f = np.float32
+    tp, cp, sp = pre["info_target_pos"], post["xpos"][:, 13], post["site_xpos"][:, 0]
+    btd = np.sqrt(((tp - cp) ** 2).sum(-1, dtype=f)).astype(f)
+    btd = np.where(btd < f(0.005), f(0), btd)
+    push = (f(1) / (f(1) + f(3) * btd)) * f(W[0])
+    site_z = np.where(sp[:, 2] < f(0.82), f(1), f(0))
+    dx, dy = tp[:, 0] - cp[:, 0], tp[:, 1] - cp[:, 1]
+    ang = np.arctan2(dy, dx + f(0.00001)).astype(f)
+    dist = np.sqrt(dx * dx + dy * dy).astype(f) + f(0.04)
+    ncp = np.stack([dx - dist * np.cos(ang).astype(f) + cp[:, 0], dy - dist * np.sin(ang).astype(f) + cp[:, 1]], -1)
+    s2c = np.sqrt(((sp[:, :2] - pre["info_new_cube_pos"]) ** 2).sum(-1, dtype=f)).astype(f)
+    s2c = np.where(s2c < f(0.042), f(0), s2c - f(0.042))
+    siet = (f(1) - np.tanh(f(5) * s2c).astype(f)) * f(W[1])
+    siet = np.where(btd < f(0.005), f(W[1]), siet)
+    health = f(W[2]) * np.abs(np.where(sp[:, 2] < f(W[3]), f(1), f(0)) - f(1))
+    reward = np.clip(push + siet + health + site_z, -100, 100)
+    done = np.where(cp[:, 2] < f(0.6), f(1), f(0))
+    obs = np.concatenate([post["qpos"][:, :6], sp, tp, cp, ncp, tp - cp, cp - sp], -1)
+    return reward, done, obs, ncp, push, siet
+
+
+def _snap(st):
+    return {k: (v.copy() if v is not None else None) for k, v in st.items()}
+
+
+def test_epilogue_matches_numpy_restatement(cube_model, oracle_mod):
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    n = 64
+    st = orc.new_state(n)
+    orc.reset(st, prng.split(prng.PRNGKey(3), n))
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        pre = _snap(st)
+        orc.step(st, rng.uniform(-1, 1, (n, 5)).astype(np.float32))
+        reward, done, obs, ncp, push, siet = _np_reward_obs(pre, st)
+        np.testing.assert_allclose(st["reward"], reward, rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(st["done"], done)
+        np.testing.assert_allclose(st["obs"], obs, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(st["info_new_cube_pos"], ncp, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(st["metrics"][:, 0], push, rtol=2e-6)
+        np.testing.assert_allclose(st["metrics"][:, 2], siet, rtol=2e-6, atol=2e-6)
+        assert np.all(st["metrics"][:, 1] == 0)          # ctrl_cost is never updated (cube_env.py:203-206)
+
+
+def test_prologue_ctrl_shaping(cube_model, oracle_mod):
+    """ctrl = clip(prev + 0.02*a); ctrl[3] = -(1.57+q1+q2); ctrl[4] = -atan2(dy, dx+1e-5)+ctrl[0]+1.5708 (cube_env.py:146-161)."""
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    n = 16
+    st = orc.new_state(n)
+    orc.reset(st, prng.split(prng.PRNGKey(4), n))
+    pre = _snap(st)
+    a = np.random.default_rng(4).uniform(-1, 1, (n, 5)).astype(np.float32)
+    orc.step(st, a)
+    f = np.float32
+    want = pre["ctrl"] + np.array([0.02, 0.02, 0.02, 0, 0], f) * a
+    want[:, 3] = -((f(1.57) + pre["qpos"][:, 1]) + pre["qpos"][:, 2])
+    dx = pre["info_target_pos"][:, 0] - pre["xpos"][:, 13, 0]
+    dy = pre["info_target_pos"][:, 1] - pre["xpos"][:, 13, 1]
+    want[:, 4] = (-np.arctan2(dy, dx + f(0.00001)).astype(f) + want[:, 0]) + f(1.5708)
+    lo = cube_model.arrays["actuator_ctrlrange"][:, 0].astype(f)
+    hi = cube_model.arrays["actuator_ctrlrange"][:, 1].astype(f)
+    np.testing.assert_allclose(st["ctrl"], np.clip(want, lo, hi), rtol=1e-6, atol=1e-6)
+
+
+def test_hand_computed_reward_cases():
+    """box_target_dis < 0.005 => push_reward = 6 and siet = 3 (cube_env.py:165-167, 194)."""
+    f = np.float32
+    tp = np.array([[0.45, 0.1, 0.82]], f)
+    pre = dict(info_target_pos=tp, info_new_cube_pos=np.array([[0.37, -0.08]], f))
+    xpos = np.zeros((1, 14, 3), f); xpos[0, 13] = tp[0] + f(0.001)
+    post = dict(xpos=xpos, site_xpos=np.array([[[0.2, 0.0, 0.9]]], f), qpos=np.zeros((1, 22), f))
+    reward, done, obs, ncp, push, siet = _np_reward_obs(pre, post)
+    assert push[0] == 6.0 and siet[0] == 3.0 and reward[0] == 6.0 + 3.0 + 1.0 + 0.0 and done[0] == 0.0
+
+
+def test_reset_follows_cube_env(cube_model, oracle_mod):
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    keys = prng.split(prng.PRNGKey(9), 8)
+    st = orc.new_state(8)
+    orc.reset(st, keys)
+    A = cube_model.arrays
+    for e, key in enumerate(keys):
+        ks = prng.split(key, 5)
+        q = A["qpos0"].astype(np.float32) + prng.uniform(ks[1], (22,), -0.01, 0.01)
+        q[:6] += np.array([0, -0.5422302, 0.45173569, 1.5718, -1.4794435, 1.1731174], np.float32)
+        q[7] = -0.033
+        tgt = prng.uniform(ks[4], (3,), np.array([0.4364427, 0.07352592, 0.82], np.float32), np.array([0.4864427, 0.12352592, 0.82], np.float32))
+        cube = prng.uniform(ks[0], (3,), np.array([0.29, -0.04, 0.82], np.float32), np.array([0.34, 0.01, 0.82], np.float32))
+        q[15:18], q[8:11] = cube, tgt
+        for a in (11, 18):
+            q[a:a + 4] /= np.linalg.norm(q[a:a + 4])           # kinematics writes the normalised quaternion back
+        np.testing.assert_allclose(st["qpos"][e], q, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(st["qvel"][e], prng.uniform(ks[2], (20,), -0.01, 0.01))
+        ctrl = np.array([0, -0.73151061, 0.455936904, -1.4794435, 1.1731174], np.float32) + prng.uniform(ks[3], (5,), -0.01, 0.01)
+        np.testing.assert_array_equal(st["ctrl"][e], ctrl)
+        np.testing.assert_allclose(st["info_target_pos"][e], tgt, atol=1e-7)
+    np.testing.assert_array_equal(st["info_new_cube_pos"], np.tile(np.float32([0.37342, -0.07989]), (8, 1)))
+    assert np.all(st["reward"] == 0) and np.all(st["done"] == 0)
+    assert np.any(st["qacc_warmstart"] != 0)            # qacc of the init forward (ctrl = 0) is the first warm start
+
+
+def test_episode_and_autoreset_wrappers(cube_model, oracle_mod):
+    """EpisodeWrapper truncation at episode_length and AutoResetWrapper restoring the cached first state
+    (brax.envs.training.wrap as called at RSR/train.py:224-229)."""
+    L = 5
+    orc = oracle_mod.Oracle(make_blob(cube_model, episode_length=L, auto_reset=True))
+    n = 8
+    st = orc.new_state(n)
+    orc.reset(st, prng.split(prng.PRNGKey(5), n))
+    first = _snap(st)
+    rng = np.random.default_rng(5)
+    for t in range(1, 2 * L + 2):
+        orc.step(st, rng.uniform(-1, 1, (n, 5)).astype(np.float32))
+        k = (t - 1) % L + 1
+        np.testing.assert_array_equal(st["info_steps"], k)
+        if k == L:
+            assert np.all(st["done"] == 1) and np.all(st["info_truncation"] == 1)
+            for f in ("qpos", "qvel", "ctrl", "qacc_warmstart", "xpos", "site_xpos", "obs"):
+                np.testing.assert_array_equal(st[f], first[f])
+            # info is NOT reset by AutoResetWrapper
+            assert not np.array_equal(st["info_new_cube_pos"], first["info_new_cube_pos"])
+        else:
+            assert np.all(st["done"] == 0) and np.all(st["info_truncation"] == 0)
+    # episode_metrics follow brax: accumulate, then multiply by (1 - previous episode_done), so the first
+    # step after a done leaves them at zero and the next one counts 1
+    em = st["info_episode_metrics"]
+    assert np.all(em[:, 1] == 0.0) and np.all(em[:, 0] == 0.0)
+    orc.step(st, rng.uniform(-1, 1, (n, 5)).astype(np.float32))
+    assert np.all(em[:, 1] == 1.0)
+    np.testing.assert_allclose(em[:, 0], st["reward"], rtol=1e-6)
+
+
+def test_unwrapped_env_has_no_episode_logic(cube_model, oracle_mod):
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    st = orc.new_state(4)
+    orc.reset(st, prng.split(prng.PRNGKey(6), 4))
+    for _ in range(3):
+        orc.step(st, np.zeros((4, 5), np.float32))
+    assert np.all(st["info_steps"] == 0) and np.all(st["info_episode_metrics"] == 0)
+
+
+def test_golden_configs0_regression(cube_model, oracle_mod):
+    g = np.load(GOLD)
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    st = orc.new_state(4)
+    orc.reset(st, g["keys"])
+    np.testing.assert_allclose(st["obs"], g["reset_obs"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(st["qacc_warmstart"], g["reset_warm"], rtol=1e-4, atol=1e-3)
+    for t in range(200):
+        orc.step(st, g["actions"][t])
+        if t < 20:
+            np.testing.assert_allclose(st["obs"], g["obs"][t], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(st["reward"], g["reward"][t], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(st["done"], g["done"][-1])
+    # teacher-forced single steps from the stored snapshots
+    for t in (0, 1, 50, 100, 199):
+        s2 = orc.new_state(4)
+        orc.reset(s2, g["keys"])
+        for f in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "info_target_pos", "info_new_cube_pos"):
+            s2[f][...] = g[f"pre{t}_{f}"]
+        orc.step(s2, g["actions"][t])
+        np.testing.assert_allclose(s2["obs"], g[f"post{t}_obs"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(s2["qpos"], g[f"post{t}_qpos"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(s2["reward"], g[f"post{t}_reward"], rtol=1e-5, atol=1e-6)
+
+
+def test_domain_randomisation_inputs(cube_model, oracle_mod):
+    from rsr_mjx_amd.envs.airbot import domain_randomize
+    n = 16
+    dr = domain_randomize(cube_model, prng.split(prng.PRNGKey(7), n))
+    A = cube_model.arrays
+    s = dr["geom_friction"][:, 16, 0] / np.float32(A["geom_friction"][16, 0])
+    assert np.all((s >= 0.68) & (s <= 1.32))
+    np.testing.assert_allclose(dr["geom_friction"][:, 16] / A["geom_friction"][16].astype(np.float32), s[:, None].repeat(3, 1), rtol=1e-6)
+    ms = dr["body_mass"][:, 13] / np.float32(0.5)
+    assert np.all((ms >= 0.84) & (ms <= 1.16)) and np.all(dr["body_mass"][:, :13] == A["body_mass"][:13].astype(np.float32))
+    ds = dr["dof_damping"][:, 0] / np.float32(0.2)
+    assert np.all((ds >= 0.92) & (ds <= 1.08)) and np.all(dr["dof_damping"][:, 8:] == 0)
+    fingers = [10, 11, 12, 13, 14, 15]
+    fs = dr["geom_friction"][:, fingers, 0]
+    assert np.allclose(fs, fs[:, :1]) and np.all((fs >= 0.76) & (fs <= 1.24))
+    # a heavier, grippier cube changes the physics: oracle with DR differs from without
+    orc = oracle_mod.Oracle(make_blob(cube_model))
+    keys = prng.split(prng.PRNGKey(8), n)
+    a, b = orc.new_state(n), orc.new_state(n, dr)
+    orc.reset(a, keys); orc.reset(b, keys)
+    act = np.random.default_rng(8).uniform(-1, 1, (n, 5)).astype(np.float32)
+    for _ in range(5):
+        orc.step(a, act); orc.step(b, act)
+    assert np.abs(a["qvel"] - b["qvel"]).max() > 1e-6
