@@ -40,7 +40,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("RSR_MJX_LIB", _build.LIB)   # override: diagnostic builds (tools/gpu_stage_profile.py)
     # torch ships its own HIP runtime; import it first so librsrmjx.so binds to the same libamdhip64
     # (two runtimes in one process do not see each other's device context).
     import torch  # noqa: F401

@@ -124,10 +124,28 @@ __device__ __forceinline__ V3 qrot(Q4 q, V3 v) { return mulv(q2m(q), v); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // ---- wave helpers (wave64) ----
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane sums use DPP (VALU latency) instead of ds_bpermute (LDS latency): quad xor-1, xor-2, then
+// half-row and row mirrors give every lane its 16-lane row sum; the four row sums meet through v_readlane.
+// Every lane ends with the same bits (the adds commute), so decisions taken on the result are wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
   return v;
+}
+__device__ __forceinline__ float rdlane(float v, int l);
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum16(v);
+  float s01 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float s23 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+              __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return s01 + s23;
 }
 __device__ __forceinline__ float rdlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -135,6 +153,27 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define WSYNC() __syncthreads()
+
+// ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
+#ifdef RSR_PROFILE
+enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
+       PS_INTEG, PS_EPILOGUE, PS_COUNT };
+struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
+__device__ __forceinline__ unsigned long long prof_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < PS_COUNT; ++i_) prof_.acc[i_] = 0; prof_.t0 = prof_now();
+#define PROF_ARG , Prof& prof_
+#define PROF_PASS , prof_
+#define PROF(stage) { unsigned long long t_ = prof_now(); prof_.acc[stage] += t_ - prof_.t0; prof_.t0 = t_; }
+#else
+#define PROF_DECL
+#define PROF_ARG
+#define PROF_PASS
+#define PROF(stage)
+#endif
 
 // ---- LDS image of one environment ----
 template <class C>
@@ -323,7 +362,7 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
     float piv = rdlane(a[k], k);
     piv = piv > 0.0f ? piv : RSR_MINVAL;
     float d = sqrtf(piv), inv = 1.0f / d;
-    a[k] = (lane == k) ? d : a[k] * inv;        // column k of L (rows >= k meaningful)
+    a[k] = (lane == k) ? inv : a[k] * inv;      // column k of L below the diagonal; the diagonal slot keeps 1/L[k][k]
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {
       float ljk = rdlane(a[k], j);
@@ -333,7 +372,7 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
   // transpose through LDS: T[k][i] = L[i][k]
   if (lane < C::NV) {
 #pragma unroll
-    for (int k = 0; k < C::NV; ++k) T[k * C::LD + lane] = (k <= lane) ? a[k] : 0.0f;
+    for (int k = 0; k < C::NV; ++k) T[k * C::LD + lane] = (k < lane) ? a[k] : 0.0f;
   }
   WSYNC();
   if (lane < C::NV) {
@@ -342,17 +381,17 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
   }
   WSYNC();
 }
-// solves L L^T x = b; lane i holds b_i in x and receives x_i
+// solves L L^T x = b; lane i holds b_i in x and receives x_i.  a[k] of lane k holds 1/L[k][k].
 template <class C>
 __device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float (&lt)[C::NV], float x, int lane) {
 #pragma unroll
   for (int k = 0; k < C::NV; ++k) {          // forward: L y = b
-    float yk = rdlane(x, k) / rdlane(a[k], k);
+    float yk = rdlane(x, k) * rdlane(a[k], k);
     x = (lane == k) ? yk : ((lane > k) ? x - a[k] * yk : x);
   }
 #pragma unroll
   for (int k = C::NV - 1; k >= 0; --k) {     // backward: L^T x = y
-    float xk = rdlane(x, k) / rdlane(a[k], k);
+    float xk = rdlane(x, k) * rdlane(a[k], k);
     x = (lane == k) ? xk : ((lane < k) ? x - lt[k] * xk : x);
   }
   return x;
@@ -719,8 +758,14 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
   if (sr0 <= 0.0f) k = -sr0 / (dmax * dmax);
   if (sr1 <= 0.0f) b = -sr1 / dmax;
   float x = fabsf(pos) / width;
-  float ia = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
-  float ib = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  float ia, ib;
+  if (power == 2.0f) {       // MuJoCo's default; x*x is the correctly rounded square, as pow(x, 2) is
+    ia = (1.0f / mid) * (x * x);
+    ib = 1.0f - (1.0f / (1.0f - mid)) * ((1.0f - x) * (1.0f - x));
+  } else {
+    ia = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
+    ib = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
+  }
   float y = x < mid ? ia : ib;
   imp = clampf(dmin + y * (dmax - dmin), dmin, dmax);
   if (x > 1.0f) imp = dmax;

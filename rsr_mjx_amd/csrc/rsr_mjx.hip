@@ -130,7 +130,8 @@ __global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs 
   WSYNC();
   float Mrow[C::NV], warm = 0.0f;
   FwdOut<C> f;
-  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr);
+  PROF_DECL
+  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
   WSYNC();
   if (lane < C::NU) s.ctrl[lane] = ctrl_init;                 // data.replace(ctrl=joint_ctrl), no re-forward
   WSYNC();
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(64) void step_kernel(DModel m, Layout L, StepArgs a
   float* rec = a.state + (size_t)e * L.rec;
   const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
   const int cube = m.env_ids[ID_CUBE], site = m.env_ids[ID_SITE];
+  PROF_DECL
   // ---- load the record ----
   for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
   float warm = 0.0f;
@@ -199,13 +201,18 @@ __global__ __launch_bounds__(64) void step_kernel(DModel m, Layout L, StepArgs a
     s.ctrl[lane] = clampf(act, m.env_ctrl_lo[lane], m.env_ctrl_hi[lane]);
   }
   WSYNC();
+  PROF(PS_LOAD)
   // ---- n_frames x mjx.step ----
   float Mrow[C::NV];
   FwdOut<C> f;
   for (int fr = 0; fr < m.n_frames; ++fr) {
+#ifdef RSR_PROFILE
+    float* dbg = nullptr;
+#else
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
-    forward<C>(m, s, lane, Mrow, warm, f, dbg);
-    integrate<C>(m, s, lane, Mrow, f);
+#endif
+    forward<C>(m, s, lane, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, s, lane, Mrow, f PROF_PASS);
     time += m.timestep;
   }
   // ---- epilogue: reward, done, obs, info (cube_env.py:164-213); derived data are from the last forward ----
@@ -268,6 +275,13 @@ __global__ __launch_bounds__(64) void step_kernel(DModel m, Layout L, StepArgs a
     store_pipeline<C>(s, rec, L, lane, warm, time);
     for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = obs_lds[t];
   }
+#ifdef RSR_PROFILE
+  PROF(PS_EPILOGUE)
+  if (a.debug && lane == 0) {      // stage cycle counters leave the kernel only through the debug buffer
+    float* d = a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7200;
+    for (int i = 0; i < PS_COUNT; ++i) d[i] = (float)prof_.acc[i];
+  }
+#endif
 }
 
 }  // namespace rsr

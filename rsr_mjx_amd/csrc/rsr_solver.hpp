@@ -58,30 +58,56 @@ __device__ __forceinline__ float rows_cost(int lane, const float (&jaref)[C::NCH
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
-template <class C>
-__device__ __forceinline__ LSPoint ls_point(int lane, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
-                                            const RowRegs (&rr)[C::NCHUNK], float g0, float g1, float g2) {
-  float q0 = 0, q1 = 0, q2 = 0;
+// Evaluates the 1-D cost model at NPT step sizes at once: per-row quadratic pieces are summed over the rows
+// owned by the lane, then the 3*NPT partial sums are reduced together (independent DPP chains overlap).
+template <class C, int NPT>
+__device__ __forceinline__ void ls_eval(int lane, const float (&alpha)[NPT], const float (&jaref)[C::NCHUNK],
+                                        const float (&jv)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK], float g0, float g1,
+                                        float g2, LSPoint (&out)[NPT]) {
+  float q[NPT][3];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) q[p][0] = q[p][1] = q[p][2] = 0.0f;
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     int r = lane + 64 * ch, kind = row_kind<C>(r);
     float ja = jaref[ch], v = jv[ch], D = rr[ch].D;
-    float x = ja + alpha * v;
-    float a0 = 0.5f * ja * ja * D, a1 = v * ja * D, a2 = 0.5f * v * v * D;
-    if (kind == 1) {
-      float f = rr[ch].floss, rf = rr[ch].R * f;
-      if (x <= -rf) { a0 = f * (-0.5f * rf - ja); a1 = -f * v; a2 = 0; }
-      else if (x >= rf) { a0 = f * (-0.5f * rf + ja); a1 = f * v; a2 = 0; }
-    } else if (kind == 2 && !(x < 0.0f)) { a0 = a1 = a2 = 0; }
-    q0 += a0; q1 += a1; q2 += a2;
+    float b0 = 0.5f * ja * ja * D, b1 = v * ja * D, b2 = 0.5f * v * v * D;
+    float f = rr[ch].floss, rf = rr[ch].R * f;
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      float x = ja + alpha[p] * v;
+      float a0 = b0, a1 = b1, a2 = b2;
+      if (kind == 1) {
+        if (x <= -rf) { a0 = f * (-0.5f * rf - ja); a1 = -f * v; a2 = 0; }
+        else if (x >= rf) { a0 = f * (-0.5f * rf + ja); a1 = f * v; a2 = 0; }
+      } else if (kind == 2 && !(x < 0.0f)) { a0 = a1 = a2 = 0; }
+      q[p][0] += a0; q[p][1] += a1; q[p][2] += a2;
+    }
   }
-  q0 = wave_sum(q0) + g0; q1 = wave_sum(q1) + g1; q2 = wave_sum(q2) + g2;
-  LSPoint p;
-  p.alpha = alpha;
-  p.cost = alpha * alpha * q2 + alpha * q1 + q0;
-  p.d0 = 2.0f * alpha * q2 + q1;
-  p.d1 = 2.0f * q2 + (q2 == 0.0f ? RSR_MINVAL : 0.0f);
-  return p;
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[p][c] = row_sum16(q[p][c]);
+  }
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    float t[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = (rdlane(q[p][c], 0) + rdlane(q[p][c], 16)) + (rdlane(q[p][c], 32) + rdlane(q[p][c], 48));
+    float q0 = t[0] + g0, q1 = t[1] + g1, q2 = t[2] + g2, al = alpha[p];
+    out[p].alpha = al;
+    out[p].cost = al * al * q2 + al * q1 + q0;
+    out[p].d0 = 2.0f * al * q2 + q1;
+    out[p].d1 = 2.0f * q2 + (q2 == 0.0f ? RSR_MINVAL : 0.0f);
+  }
+}
+template <class C>
+__device__ __forceinline__ LSPoint ls_point(int lane, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
+                                            const RowRegs (&rr)[C::NCHUNK], float g0, float g1, float g2) {
+  float al[1] = {alpha};
+  LSPoint o[1];
+  ls_eval<C, 1>(lane, al, jaref, jv, rr, g0, g1, g2, o);
+  return o[0];
 }
 
 // qfrc_constraint = J^T force ; rows with zero force are skipped (wave-uniform loop over a ballot)
@@ -150,7 +176,7 @@ struct SolveStats { int niter, ls_total; };
 template <class C>
 __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const RowRegs (&rr)[C::NCHUNK],
                       const float (&Mrow)[C::NV], float fs, float a0, float warm, float& qacc_out, float& qfc_out,
-                      SolveStats& st) {
+                      SolveStats& st PROF_ARG) {
   const bool dofl = lane < C::NV;
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
   float a[C::NV], lt[C::NV];
@@ -179,8 +205,10 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
   cost = rc + gauss;
   float qfc = jt_force<C>(s, lane, nefc, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
+  PROF(PS_SOLVE_INIT)
   hessian_factor<C>(s, lane, nefc, hw, a, lt);
   float search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+  PROF(PS_HESS)
   const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
   while (true) {
@@ -199,6 +227,19 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     jdot<C>(s, lane, nefc, search, jv);
     float g1 = wave_sum(search * Ma) - wave_sum(search * fs);
     float g2 = 0.5f * wave_sum(search * mv);
+    // fp32 noise floor of the 1-D derivative: d0(alpha) = 2 alpha q2 + q1 is a sum of up to NEFC terms, so values
+    // below eps * (sum |q1 terms| + 2 |alpha| sum |q2 terms|) are indistinguishable from zero.  MJX's gtol
+    // (tolerance * ls_tolerance * |search| * scale ~ 1e-6) is below that floor in fp32 and the reference loop
+    // then dithers until no bracket update happens; stopping at the floor changes nothing above rounding noise.
+    float n1 = 0.0f, n2 = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < C::NCHUNK; ++ch) {
+      n1 += fabsf(jv[ch] * jaref[ch] * rr[ch].D) + (rr[ch].floss > 0.0f ? fabsf(rr[ch].floss * jv[ch]) : 0.0f);
+      n2 += 0.5f * jv[ch] * jv[ch] * rr[ch].D;
+    }
+    n1 = wave_sum(n1) + wave_sum(fabsf(search * Ma)) + wave_sum(fabsf(search * fs));
+    n2 = wave_sum(n2) + fabsf(g2);
+    const float NOISE = 1.1920929e-7f;
     LSPoint p0 = ls_point<C>(lane, 0.0f, jaref, jv, rr, gauss, g1, g2);
     LSPoint lo = ls_point<C>(lane, p0.alpha - p0.d0 / p0.d1, jaref, jv, rr, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
@@ -206,12 +247,15 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     while (true) {
       bool ldone = it >= m.ls_iterations;
       ldone |= !swap;
-      ldone |= (lo.d0 < 0.0f) && (lo.d0 > -gtol);
-      ldone |= (hi.d0 > 0.0f) && (hi.d0 < gtol);
+      float tol_lo = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(lo.alpha) * n2));
+      float tol_hi = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(hi.alpha) * n2));
+      ldone |= (lo.d0 < 0.0f) && (lo.d0 > -tol_lo);
+      ldone |= (hi.d0 > 0.0f) && (hi.d0 < tol_hi);
       if (uniform_i(ldone)) break;
-      LSPoint lo_next = ls_point<C>(lane, lo.alpha - lo.d0 / lo.d1, jaref, jv, rr, gauss, g1, g2);
-      LSPoint hi_next = ls_point<C>(lane, hi.alpha - hi.d0 / hi.d1, jaref, jv, rr, gauss, g1, g2);
-      LSPoint mid = ls_point<C>(lane, 0.5f * (lo.alpha + hi.alpha), jaref, jv, rr, gauss, g1, g2);
+      float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      LSPoint p3[3];
+      ls_eval<C, 3>(lane, al3, jaref, jv, rr, gauss, g1, g2, p3);
+      LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
       bool s1 = (lo.d0 > 0.0f) || (lo.d0 < lo_next.d0);
       if (s1) lo = lo_next;
       bool s2 = (mid.d0 < 0.0f) && (lo.d0 < mid.d0);
@@ -224,6 +268,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
       ++it;
     }
     ls_total += it;
+    PROF(PS_LS)
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
@@ -237,8 +282,10 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     prev_cost = cost; cost = rc + gauss;
     qfc = jt_force<C>(s, lane, nefc, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
+    PROF(PS_UPD)
     hessian_factor<C>(s, lane, nefc, hw, a, lt);
     search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+    PROF(PS_HESS)
     ++iter;
   }
   st.niter = iter; st.ls_total = ls_total;
@@ -253,16 +300,21 @@ struct FwdOut { float qacc, qfc, fsmooth; int nefc; SolveStats st; };
 // warm_i is read and replaced by the solver's qacc (qacc_warmstart <- qacc).
 template <class C>
 __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
-                        float* dbg) {
+                        float* dbg PROF_ARG) {
   kinematics<C>(m, s, lane);
+  PROF(PS_KIN)
   com_crb_mass<C>(m, s, lane);
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) Mrow[j] = lane < C::NV ? s.M[lane * C::LD + j] : 0.0f;
+  PROF(PS_COMCRB)
   collision<C>(m, s, lane);
+  PROF(PS_COLL)
   RowRegs rr[C::NCHUNK];
   int nefc = make_constraint<C>(m, s, lane, rr);
+  PROF(PS_ROWS)
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
   float fs = smooth_forces<C>(m, s, lane, qvel_i, 0.0f);
+  PROF(PS_SMOOTH)
   // qacc_smooth = M^-1 qfrc_smooth
   float a[C::NV], lt[C::NV];
 #pragma unroll
@@ -270,7 +322,8 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
   chol_factor<C>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, fs, lane) : 0.0f;
   out.fsmooth = fs; out.nefc = nefc;
-  solve<C>(m, s, lane, nefc, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st);
+  PROF(PS_CHOLM)
+  solve<C>(m, s, lane, nefc, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
     if (lane == 0) {
@@ -305,7 +358,7 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
 
 // integrate one substep after forward(): implicitfast / Euler, then _advance
 template <class C>
-__device__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f) {
+__device__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
   float qacc = f.qacc;
   bool implicit = m.integrator == INT_IMPLICITFAST;
   if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
@@ -343,6 +396,7 @@ __device__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&M
     }
   }
   WSYNC();
+  PROF(PS_INTEG)
 }
 
 }  // namespace rsr

@@ -1,0 +1,35 @@
+"""Per-stage cycle shares of the step kernel from the -DRSR_PROFILE diagnostic build (s_memtime stamps).
+Never quote this build's run time: read the shares only."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "rsr_mjx_amd", "csrc")
+PROF = os.path.join(CSRC, "librsrmjx_prof.so")
+if not os.path.exists(PROF) or "--rebuild" in sys.argv:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRSR_PROFILE",
+                           "-o", PROF, os.path.join(CSRC, "rsr_mjx.hip")])
+os.environ["RSR_MJX_LIB"] = PROF
+import numpy as np
+import torch
+from rsr_mjx_amd import prng
+from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
+
+NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "smooth_forces", "chol_M+solve",
+         "solver_init", "hessian+factor+solve", "linesearch", "update_constraint", "integrate", "epilogue+store"]
+n = 8192
+envdef = AirbotPlayBase()
+dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
+env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
+s = env.reset(prng.split(prng.PRNGKey(0), n))
+dbg = env.enable_debug(True)
+tot = np.zeros(len(NAMES))
+for t in range(40):
+    env.step(s, torch.clamp(torch.randn(n, 5, device="cuda"), -1, 1))
+    if t >= 10:
+        torch.cuda.synchronize()
+        tot += dbg[:, 7200:7200 + len(NAMES)].double().mean(dim=0).cpu().numpy()
+tot /= 30
+print(f"mean cycles per env-step (wave lifetime, 4 substeps): {tot.sum():.0f}")
+for nm, v in zip(NAMES, tot):
+    print(f"  {nm:24s} {v:10.0f}  {100 * v / tot.sum():5.1f} %")
+print("stats mean [niter ls ncon drop]", env.view("stats").float().mean(dim=0).tolist())
