@@ -28,7 +28,7 @@ enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
 
 // ---- device view of the model blob (pointers into one device copy of the blob) ----
 struct DModel {
-  const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
+  const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_depth;
   const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
   const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited, *jnt_actfrclimited;
   const float *jnt_pos, *jnt_axis, *jnt_range, *jnt_actfrcrange, *jnt_solref, *jnt_solimp, *jnt_margin;
@@ -51,7 +51,7 @@ struct DModel {
   const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
   float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
-  int nfric, nlimit;
+  int nfric, nlimit, maxdepth;
   int env_kind, n_frames, episode_length, wrap_flags;
 };
 
@@ -194,76 +194,92 @@ struct Smem {
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int lim_jnt[C::NL > 0 ? C::NL : 1];
-  // constraint rows; the clip scratch of the collision stage aliases J
-  float J[C::NEFC * C::LD];
-  float rw[C::NEFC];                                 // per-row weight D*active (Hessian), then force (J^T f)
+  // constraint rows; the clip scratch of the collision stage aliases J.  Row NEFC is a permanent null row
+  // (zero weight) that pads the compacted row lists to a multiple of four.
+  float J[(C::NEFC + 1) * C::LD];
+  float rw[C::NEFC + 4];                             // per-row weight D*active (Hessian) or force (J^T f)
+  int rlist[C::NEFC + 4];                            // compacted indices of the rows with non-zero weight
 };
 
 // =====================================================================================
-// stage 1: kinematics (MJX smooth.kinematics).  The chain is serial; every lane walks it
-// redundantly (wave-uniform control flow, scalar model loads), lane 0 publishes to LDS.
+// stage 1: kinematics (MJX smooth.kinematics).  Lane b first builds body b's transform relative to its
+// parent, joint included (one sincos for all hinges at once); the tree is then composed level by level,
+// each lane fetching its parent's pose with a cross-lane read, so the serial chain is maxdepth short
+// register-only steps instead of nbody LDS round trips.  Bodies carry at most one joint (checked on the host).
 // =====================================================================================
 template <class C>
 __device__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
-  if (lane == 0) { st3(s.xpos, v3(0, 0, 0)); st4(s.xquat, Q4{1, 0, 0, 0}); }
-  WSYNC();
-  for (int b = 1; b < C::NB; ++b) {
-    int p = m.body_parentid[b];
-    Q4 pq = ld4(&s.xquat[4 * p]);
-    V3 pos = ld3(&s.xpos[3 * p]) + qrot(pq, ld3(&m.body_pos[3 * b]));
-    Q4 q = qmul(pq, ld4(&m.body_quat[4 * b]));
-    int jn = m.body_jntnum[b], ja0 = m.body_jntadr[b];
-    for (int k = 0; k < jn; ++k) {
-      int j = ja0 + k, qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
-      if (jt == JNT_FREE) {
-        pos = ld3(&s.qpos[qa]);
-        q = ld4(&s.qpos[qa + 3]);
-        float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-        if (n < RSR_MINVAL) q = Q4{1, 0, 0, 0};
-        else { float inv = 1.0f / n; q = Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv}; }
-        if (lane == 0) { st3(&s.xanchor[3 * j], pos); st3(&s.xaxis[3 * j], v3(0, 0, 1)); st4(&s.qpos[qa + 3], q); }
+  static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64, "one lane per body / geom / joint");
+  const int b = lane < C::NB ? lane : 0;
+  const int parent = m.body_parentid[b], depth = lane < C::NB ? m.body_depth[b] : -1;
+  V3 bp = ld3(&m.body_pos[3 * b]);
+  Q4 bq = ld4(&m.body_quat[4 * b]);
+  V3 lp = bp; Q4 lq = bq;
+  if (lane < C::NB && m.body_jntnum[b] > 0) {
+    int j = m.body_jntadr[b], qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
+    if (jt == JNT_FREE) {
+      lp = ld3(&s.qpos[qa]);
+      lq = ld4(&s.qpos[qa + 3]);
+      float n = sqrtf(lq.w * lq.w + lq.x * lq.x + lq.y * lq.y + lq.z * lq.z);
+      if (n < RSR_MINVAL) lq = Q4{1, 0, 0, 0};
+      else { float inv = 1.0f / n; lq = Q4{lq.w * inv, lq.x * inv, lq.y * inv, lq.z * inv}; }
+      st4(&s.qpos[qa + 3], lq);                    // MJX writes the normalised quaternion back
+    } else {
+      V3 jp = ld3(&m.jnt_pos[3 * j]), jax = ld3(&m.jnt_axis[3 * j]);
+      float dq = s.qpos[qa] - m.qpos0[qa];
+      if (jt == JNT_HINGE) {
+        float sn, cs;
+        sincosf(dq * 0.5f, &sn, &cs);
+        Q4 qloc = Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn};
+        lq = qmul(bq, qloc);
+        lp = bp + qrot(bq, jp - qrot(qloc, jp));
       } else {
-        V3 jp = ld3(&m.jnt_pos[3 * j]), jax = ld3(&m.jnt_axis[3 * j]);
-        V3 anchor = qrot(q, jp) + pos, axis = qrot(q, jax);
-        if (lane == 0) { st3(&s.xanchor[3 * j], anchor); st3(&s.xaxis[3 * j], axis); }
-        float dq = s.qpos[qa] - m.qpos0[qa];
-        if (jt == JNT_HINGE) {
-          float sn, cs;
-          sincosf(dq * 0.5f, &sn, &cs);
-          q = qmul(q, Q4{cs, jax.x * sn, jax.y * sn, jax.z * sn});
-          pos = anchor - qrot(q, jp);
-        } else {
-          pos = pos + axis * dq;
-        }
+        lp = bp + qrot(bq, jax * dq);
       }
     }
-    if (lane == 0) { st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q); }
-    WSYNC();
   }
-  // frames of bodies / inertial frames / geoms / sites: one lane each
+  // compose down the tree: after level d every body of depth <= d holds its world pose
+  V3 pos = lane == 0 ? v3(0, 0, 0) : lp;
+  Q4 q = lane == 0 ? Q4{1, 0, 0, 0} : lq;
+  for (int d = 1; d <= m.maxdepth; ++d) {
+    V3 pp = v3(__shfl(pos.x, parent), __shfl(pos.y, parent), __shfl(pos.z, parent));
+    Q4 pq = Q4{__shfl(q.w, parent), __shfl(q.x, parent), __shfl(q.y, parent), __shfl(q.z, parent)};
+    if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
+  }
   if (lane < C::NB) {
-    int b = lane;
-    Q4 q = ld4(&s.xquat[4 * b]);
+    st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q);
     M33 R = q2m(q);
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.xmat[9 * b + c] = R.m[c];
-    st3(&s.xipos[3 * b], ld3(&s.xpos[3 * b]) + mulv(R, ld3(&m.body_ipos[3 * b])));
+    st3(&s.xipos[3 * b], pos + mulv(R, ld3(&m.body_ipos[3 * b])));
     M33 Ri = q2m(qmul(q, ld4(&m.body_iquat[4 * b])));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.ximat[9 * b + c] = Ri.m[c];
   }
+  WSYNC();
+  if (lane < C::NJ) {          // joint anchors / axes in the world frame (frame of the body before the joint acts)
+    int j = lane, jb = m.jnt_bodyid[j], jpar = m.body_parentid[jb];
+    if (m.jnt_type[j] == JNT_FREE) {
+      st3(&s.xanchor[3 * j], ld3(&s.xpos[3 * jb])); st3(&s.xaxis[3 * j], v3(0, 0, 1));
+    } else {
+      Q4 pq = ld4(&s.xquat[4 * jpar]);
+      Q4 qpre = qmul(pq, ld4(&m.body_quat[4 * jb]));
+      V3 ppre = ld3(&s.xpos[3 * jpar]) + qrot(pq, ld3(&m.body_pos[3 * jb]));
+      st3(&s.xanchor[3 * j], ppre + qrot(qpre, ld3(&m.jnt_pos[3 * j])));
+      st3(&s.xaxis[3 * j], qrot(qpre, ld3(&m.jnt_axis[3 * j])));
+    }
+  }
   if (lane < C::NG) {
-    int g = lane, b = m.geom_bodyid[g];
-    Q4 q = ld4(&s.xquat[4 * b]);
-    M33 R = q2m(q);
-    st3(&s.gpos[3 * g], ld3(&s.xpos[3 * b]) + mulv(R, ld3(&m.geom_pos[3 * g])));
-    M33 Rg = q2m(qmul(q, ld4(&m.geom_quat[4 * g])));
+    int g = lane, gb = m.geom_bodyid[g];
+    Q4 gq = ld4(&s.xquat[4 * gb]);
+    st3(&s.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.xmat[9 * gb], ld3(&m.geom_pos[3 * g])));
+    M33 Rg = q2m(qmul(gq, ld4(&m.geom_quat[4 * g])));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.gmat[9 * g + c] = Rg.m[c];
   }
   if (lane < C::NS) {
-    int b = m.site_bodyid[lane];
-    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * b]) + qrot(ld4(&s.xquat[4 * b]), ld3(&m.site_pos[3 * lane])));
+    int sb = m.site_bodyid[lane];
+    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.xmat[9 * sb], ld3(&m.site_pos[3 * lane])));
   }
   WSYNC();
 }
@@ -361,7 +377,8 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
   for (int k = 0; k < C::NV; ++k) {
     float piv = rdlane(a[k], k);
     piv = piv > 0.0f ? piv : RSR_MINVAL;
-    float d = sqrtf(piv), inv = 1.0f / d;
+    float inv = __builtin_amdgcn_rsqf(piv);     // v_rsq_f32 (1 ulp) + one Newton step: 1/sqrt(piv) without the IEEE sqrt/div sequences
+    inv = inv * (1.5f - 0.5f * piv * inv * inv);
     a[k] = (lane == k) ? inv : a[k] * inv;      // column k of L below the diagonal; the diagonal slot keeps 1/L[k][k]
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {

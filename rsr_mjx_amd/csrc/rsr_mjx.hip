@@ -57,6 +57,8 @@ __device__ __forceinline__ float uniform_from_bits(uint32_t b, float lo, float h
 // ---------------------------------------------------------------- record I/O
 template <class C>
 __device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, int e, int lane) {
+  if (lane < C::LD) s.J[C::NEFC * C::LD + lane] = 0.0f;      // the null row and its zero weight
+  if (lane < 4) s.rw[C::NEFC + lane] = 0.0f;
   for (int t = lane; t < C::NG * 3; t += 64) s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + t] : m.geom_friction[t];
   if (lane < C::NB) s.mass[lane] = a.dr_body_mass ? a.dr_body_mass[(size_t)e * C::NB + lane] : m.body_mass[lane];
   if (lane < C::NV) {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs 
 
 // ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
 template <class C>
-__global__ __launch_bounds__(64) void step_kernel(DModel m, Layout L, StepArgs a) {
+__global__ __launch_bounds__(64, 2) void step_kernel(DModel m, Layout L, StepArgs a) {
   __shared__ Smem<C> s;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
@@ -366,6 +368,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
             d.njnt == C::NJ && d.ngeom == C::NG && d.nsite == C::NS && d.npair == C::NP && d.neq == C::NEQ && c2 &&
             c2[0] == C::NF && c2[1] == C::NL && d.obs_dim == C::OBS && d.nmetrics == C::NMET;
   if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube)"); }
+  if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
   for (int i = 0; i < npc; ++i) if (pc[i] != 4) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: only condim-4 contact pairs are built"); }
   int nea = 0; const int* ea = static_cast<const int*>(m->find("eq_active0", &nea));
@@ -388,7 +391,7 @@ extern "C" void rsr_model_destroy(rsr_model* m) { delete m; }
 
 static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
 #define P(T, name) { ptrdiff_t o = m->offset_of(#name); if (o < 0) return fail(RSR_ERR_ARG, "blob lacks field " #name); dm.name = reinterpret_cast<const T*>(dbase + o); }
-  P(int, body_parentid) P(int, body_rootid) P(int, body_jntnum) P(int, body_jntadr) P(int, body_dofnum) P(int, body_dofadr)
+  P(int, body_parentid) P(int, body_rootid) P(int, body_jntnum) P(int, body_jntadr) P(int, body_dofnum) P(int, body_dofadr) P(int, body_depth)
   P(float, body_pos) P(float, body_quat) P(float, body_ipos) P(float, body_iquat) P(float, body_mass) P(float, body_inertia) P(float, body_invweight0)
   P(int, jnt_type) P(int, jnt_qposadr) P(int, jnt_dofadr) P(int, jnt_bodyid) P(int, jnt_limited) P(int, jnt_actfrclimited)
   P(float, jnt_pos) P(float, jnt_axis) P(float, jnt_range) P(float, jnt_actfrcrange) P(float, jnt_solref) P(float, jnt_solimp) P(float, jnt_margin)
@@ -413,7 +416,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   dm.meaninertia = F("stat_meaninertia")[0];
   dm.iterations = I("opt_iterations")[0]; dm.ls_iterations = I("opt_ls_iterations")[0]; dm.integrator = I("opt_integrator")[0];
   dm.disable_eulerdamp = I("opt_disable_eulerdamp")[0]; dm.disable_refsafe = I("opt_disable_refsafe")[0];
-  dm.nfric = I("counts2")[0]; dm.nlimit = I("counts2")[1];
+  dm.nfric = I("counts2")[0]; dm.nlimit = I("counts2")[1]; dm.maxdepth = I("counts2")[2];
   const int* ei = I("env_int");
   dm.env_kind = ei[0]; dm.n_frames = ei[1]; dm.episode_length = ei[2]; dm.wrap_flags = ei[3];
   return RSR_OK;

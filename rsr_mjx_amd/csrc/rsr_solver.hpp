@@ -21,9 +21,10 @@ __device__ __forceinline__ void jdot(const Smem<C>& s, int lane, int nefc, float
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     int r = lane + 64 * ch;
     float acc = 0;
-    if (r < nefc) {
+    if (64 * ch < nefc) {                     // wave-uniform: chunks past the last row cost nothing
+      int rr_ = r < nefc ? r : C::NEFC;       // padding lanes read the null row
 #pragma unroll
-      for (int i = 0; i < C::NV; ++i) acc += s.J[r * C::LD + i] * vb[i];
+      for (int i = 0; i < C::NV; ++i) acc += s.J[rr_ * C::LD + i] * vb[i];
     }
     out[ch] = acc;
   }
@@ -35,11 +36,13 @@ __device__ __forceinline__ int row_kind(int r) { return r < C::NEQ ? 0 : (r < C:
 
 // cost of the constraint rows at Jaref; optionally emits force and Hessian weight per row
 template <class C>
-__device__ __forceinline__ float rows_cost(int lane, const float (&jaref)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK],
+__device__ __forceinline__ float rows_cost(int lane, int nefc, const float (&jaref)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK],
                                            float (&force)[C::NCHUNK], float (&hw)[C::NCHUNK]) {
   float cost = 0;
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    force[ch] = 0.0f; hw[ch] = 0.0f;
+    if (64 * ch >= nefc) continue;            // wave-uniform
     int r = lane + 64 * ch, kind = row_kind<C>(r);
     float x = jaref[ch], D = rr[ch].D, f = 0, w = 0;
     bool act;
@@ -61,7 +64,7 @@ struct LSPoint { float alpha, cost, d0, d1; };
 // Evaluates the 1-D cost model at NPT step sizes at once: per-row quadratic pieces are summed over the rows
 // owned by the lane, then the 3*NPT partial sums are reduced together (independent DPP chains overlap).
 template <class C, int NPT>
-__device__ __forceinline__ void ls_eval(int lane, const float (&alpha)[NPT], const float (&jaref)[C::NCHUNK],
+__device__ __forceinline__ void ls_eval(int lane, int nefc, const float (&alpha)[NPT], const float (&jaref)[C::NCHUNK],
                                         const float (&jv)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK], float g0, float g1,
                                         float g2, LSPoint (&out)[NPT]) {
   float q[NPT][3];
@@ -69,6 +72,7 @@ __device__ __forceinline__ void ls_eval(int lane, const float (&alpha)[NPT], con
   for (int p = 0; p < NPT; ++p) q[p][0] = q[p][1] = q[p][2] = 0.0f;
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    if (64 * ch >= nefc) continue;            // wave-uniform
     int r = lane + 64 * ch, kind = row_kind<C>(r);
     float ja = jaref[ch], v = jv[ch], D = rr[ch].D;
     float b0 = 0.5f * ja * ja * D, b1 = v * ja * D, b2 = 0.5f * v * v * D;
@@ -102,31 +106,46 @@ __device__ __forceinline__ void ls_eval(int lane, const float (&alpha)[NPT], con
   }
 }
 template <class C>
-__device__ __forceinline__ LSPoint ls_point(int lane, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
+__device__ __forceinline__ LSPoint ls_point(int lane, int nefc, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
                                             const RowRegs (&rr)[C::NCHUNK], float g0, float g1, float g2) {
   float al[1] = {alpha};
   LSPoint o[1];
-  ls_eval<C, 1>(lane, al, jaref, jv, rr, g0, g1, g2, o);
+  ls_eval<C, 1>(lane, nefc, al, jaref, jv, rr, g0, g1, g2, o);
   return o[0];
 }
 
-// qfrc_constraint = J^T force ; rows with zero force are skipped (wave-uniform loop over a ballot)
+// Publishes per-row weights to LDS and compacts the indices of the non-zero ones (ballot + prefix popcount);
+// the list is padded with the null row so that consumers can walk it four rows at a time.
 template <class C>
-__device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, const float (&force)[C::NCHUNK]) {
+__device__ __forceinline__ int publish_rows(Smem<C>& s, int lane, int nefc, const float (&w)[C::NCHUNK]) {
   WSYNC();
-#pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = force[ch]; }
-  WSYNC();
-  float acc = 0;
+  int base = 0;
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
-    unsigned long long mask = __ballot(force[ch] != 0.0f && (lane + 64 * ch) < nefc);
-    while (mask) {
-      int r = __builtin_ctzll(mask) + 64 * ch; mask &= mask - 1;
-      if (lane < C::NV) acc += s.J[r * C::LD + lane] * s.rw[r];
-    }
+    int r = lane + 64 * ch;
+    bool on = r < nefc && w[ch] != 0.0f;
+    if (r < nefc) s.rw[r] = w[ch];
+    unsigned long long mask = __ballot(on);
+    if (on) s.rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = r;
+    base += __popcll(mask);
   }
-  return acc;
+  if (lane < 4) s.rlist[base + lane] = C::NEFC;
+  WSYNC();
+  return base;
+}
+
+// qfrc_constraint = J^T force over the rows with non-zero force, four rows per trip
+template <class C>
+__device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, const float (&force)[C::NCHUNK]) {
+  const int n = publish_rows<C>(s, lane, nefc, force);
+  const int col = lane < C::NV ? lane : 0;
+  float acc0 = 0, acc1 = 0;
+  for (int k = 0; k < n; k += 4) {
+    int r0 = s.rlist[k], r1 = s.rlist[k + 1], r2 = s.rlist[k + 2], r3 = s.rlist[k + 3];
+    acc0 += s.J[r0 * C::LD + col] * s.rw[r0]; acc1 += s.J[r1 * C::LD + col] * s.rw[r1];
+    acc0 += s.J[r2 * C::LD + col] * s.rw[r2]; acc1 += s.J[r3 * C::LD + col] * s.rw[r3];
+  }
+  return lane < C::NV ? acc0 + acc1 : 0.0f;
 }
 
 // H = M + J^T diag(hw) J as 2x2 blocks (lane = block of the lower triangle), then factor.
@@ -136,10 +155,7 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, c
   constexpr int NBLK = (C::NV + 1) / 2;
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
-  WSYNC();
-#pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = hw[ch]; }
-  WSYNC();
+  const int n = publish_rows<C>(s, lane, nefc, hw);
   int bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
   int bj = lane - bi * (bi + 1) / 2;
@@ -147,11 +163,10 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, c
   int i0 = blk ? 2 * bi : 0, j0 = blk ? 2 * bj : 0;
   float h00 = s.M[i0 * C::LD + j0], h01 = s.M[i0 * C::LD + j0 + 1];
   float h10 = s.M[(i0 + 1) * C::LD + j0], h11 = s.M[(i0 + 1) * C::LD + j0 + 1];
+  for (int k = 0; k < n; k += 4) {
 #pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) {
-    unsigned long long mask = __ballot(hw[ch] != 0.0f && (lane + 64 * ch) < nefc);
-    while (mask) {
-      int r = __builtin_ctzll(mask) + 64 * ch; mask &= mask - 1;
+    for (int u = 0; u < 4; ++u) {
+      int r = s.rlist[k + u];
       const float* Jr = &s.J[r * C::LD];
       float w = s.rw[r];
       float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
@@ -185,13 +200,13 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
   jdot<C>(s, lane, nefc, warm, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
-  float cost_w = rows_cost<C>(lane, jaref, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_w - fs) * (warm - a0) : 0.0f);
+  float cost_w = rows_cost<C>(lane, nefc, jaref, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_w - fs) * (warm - a0) : 0.0f);
   float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
   float jar_s[C::NCHUNK];
   jdot<C>(s, lane, nefc, a0, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
-  float cost_s = rows_cost<C>(lane, jar_s, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_s - fs) * (a0 - a0) : 0.0f);
+  float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_s - fs) * (a0 - a0) : 0.0f);
   const bool use_warm = cost_w < cost_s;
   float qacc = use_warm ? warm : a0, Ma = use_warm ? Ma_w : Ma_s;
   if (!use_warm) {
@@ -200,7 +215,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
   }
   // --- context at the start point ---
   float gauss, cost, prev_cost = INFINITY;
-  float rc = rows_cost<C>(lane, jaref, rr, force, hw);
+  float rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
   gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
   cost = rc + gauss;
   float qfc = jt_force<C>(s, lane, nefc, force);
@@ -240,8 +255,8 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     n1 = wave_sum(n1) + wave_sum(fabsf(search * Ma)) + wave_sum(fabsf(search * fs));
     n2 = wave_sum(n2) + fabsf(g2);
     const float NOISE = 1.1920929e-7f;
-    LSPoint p0 = ls_point<C>(lane, 0.0f, jaref, jv, rr, gauss, g1, g2);
-    LSPoint lo = ls_point<C>(lane, p0.alpha - p0.d0 / p0.d1, jaref, jv, rr, gauss, g1, g2), hi;
+    LSPoint p0 = ls_point<C>(lane, nefc, 0.0f, jaref, jv, rr, gauss, g1, g2);
+    LSPoint lo = ls_point<C>(lane, nefc, p0.alpha - p0.d0 / p0.d1, jaref, jv, rr, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     bool swap = true; int it = 0;
     while (true) {
@@ -254,7 +269,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
       if (uniform_i(ldone)) break;
       float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
-      ls_eval<C, 3>(lane, al3, jaref, jv, rr, gauss, g1, g2, p3);
+      ls_eval<C, 3>(lane, nefc, al3, jaref, jv, rr, gauss, g1, g2, p3);
       LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
       bool s1 = (lo.d0 > 0.0f) || (lo.d0 < lo_next.d0);
       if (s1) lo = lo_next;
@@ -277,7 +292,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
       for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] += alpha * jv[ch];
     }
     // ---------------- update constraint + gradient ----------------
-    rc = rows_cost<C>(lane, jaref, rr, force, hw);
+    rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
     gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
     prev_cost = cost; cost = rc + gauss;
     qfc = jt_force<C>(s, lane, nefc, force);

@@ -93,6 +93,7 @@ def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
                         only that joint's three translational dofs; empty for free translations)
       body_dofmask[b] : dofs on the chain from the root to body b, b's own included
       body_submask[b] : bodies in the subtree of b, b included
+      body_depth[b]   : tree depth (world = 0); kinematics composes poses level by level
       fric_dofs       : dofs with frictionloss > 0 (constraint rows exist for them)
       limit_jnts      : limited hinge/slide joints
     """
@@ -129,7 +130,10 @@ def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
             sub[int(A["body_parentid"][b])] |= sub[b]
     fric = np.array([i for i in range(nv) if A["dof_frictionloss"][i] > 0], dtype=np.int32)
     lim = np.array([j for j in range(m.njnt) if A["jnt_limited"][j] and A["jnt_type"][j] in (2, 3)], dtype=np.int32)
+    depth = np.zeros(nb, dtype=np.int32)
+    for b in range(1, nb):
+        depth[b] = depth[int(A["body_parentid"][b])] + 1
     as_i32 = lambda a: a.astype(np.uint32).view(np.int32)
     return dict(dof_ancmask=as_i32(anc), dof_velmask=as_i32(vel), body_dofmask=as_i32(bdof),
-                body_submask=as_i32(sub), fric_dofs=fric, limit_jnts=lim,
-                counts2=np.array([len(fric), len(lim)], dtype=np.int32))
+                body_submask=as_i32(sub), fric_dofs=fric, limit_jnts=lim, body_depth=depth,
+                counts2=np.array([len(fric), len(lim), int(depth.max()), int(A["body_jntnum"].max())], dtype=np.int32))
