@@ -176,29 +176,40 @@ __device__ __forceinline__ unsigned long long prof_now() {
 #endif
 
 // ---- LDS image of one environment ----
+// Two phases of a forward pass never overlap in time and share one region (union X):
+//   phase A (kinematics .. collision): body/geom frames, spatial inertias, velocity-stage scratch, clip slots
+//   phase B (constraint rows .. solve): the constraint Jacobian
+// What both phases (or the env epilogue) need stays outside the union.
+constexpr int NSLOT = 16;                              // clip-scratch slots handed out to penetrating pairs
+template <class C>
+struct PhaseA {
+  float xquat[C::NB * 4], xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
+  float xanchor[C::NJ * 3], xaxis[C::NJ * 3];
+  float gpos[C::NG * 3], gmat[C::NG * 9];
+  float cinert[C::NB * 10], crb[C::NB * 10];
+  float cvel[C::NB * 6], cdofdot[C::NV * 6], cfrc[C::NB * 6], cfrcsum[C::NB * 6];
+  float clip[NSLOT * 48];
+};
+template <class C>
+struct PhaseB {
+  float J[(C::NEFC + 1) * C::LD];                      // row NEFC is the null row (zero weight) padding row lists
+};
 template <class C>
 struct Smem {
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
   float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
-  // position stage
-  float xpos[C::NB * 3], xquat[C::NB * 4], xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
-  float xanchor[C::NJ * 3], xaxis[C::NJ * 3];
-  float gpos[C::NG * 3], gmat[C::NG * 9], spos[C::NS * 3];
-  float com[C::NB * 3], cinert[C::NB * 10], crb[C::NB * 10], cdof[C::NV * 6], cdofdot[C::NV * 6];
-  float cvel[C::NB * 6], cacc[C::NB * 6], cfrc[C::NB * 6], cfrcsum[C::NB * 6];
+  float xpos[C::NB * 3], spos[C::NS * 3];              // also read by the env epilogue
+  float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
   float M[C::NV * C::LD], T[C::NV * C::LD];
-  float vq[C::NV];                                   // broadcast buffer for one per-dof vector
   // contacts (active only)
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int lim_jnt[C::NL > 0 ? C::NL : 1];
-  // constraint rows; the clip scratch of the collision stage aliases J.  Row NEFC is a permanent null row
-  // (zero weight) that pads the compacted row lists to a multiple of four.
-  float J[(C::NEFC + 1) * C::LD];
-  float rw[C::NEFC + 4];                             // per-row weight D*active (Hessian) or force (J^T f)
-  int rlist[C::NEFC + 4];                            // compacted indices of the rows with non-zero weight
+  float rw[C::NEFC + 4];                               // per-row weight D*active (Hessian) or force (J^T f)
+  int rlist[C::NEFC + 4];                              // compacted indices of the rows with non-zero weight
+  union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
 
 // =====================================================================================
@@ -247,39 +258,39 @@ __device__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
     if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
   }
   if (lane < C::NB) {
-    st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q);
+    st3(&s.xpos[3 * b], pos); st4(&s.x.a.xquat[4 * b], q);
     M33 R = q2m(q);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) s.xmat[9 * b + c] = R.m[c];
-    st3(&s.xipos[3 * b], pos + mulv(R, ld3(&m.body_ipos[3 * b])));
+    for (int c = 0; c < 9; ++c) s.x.a.xmat[9 * b + c] = R.m[c];
+    st3(&s.x.a.xipos[3 * b], pos + mulv(R, ld3(&m.body_ipos[3 * b])));
     M33 Ri = q2m(qmul(q, ld4(&m.body_iquat[4 * b])));
 #pragma unroll
-    for (int c = 0; c < 9; ++c) s.ximat[9 * b + c] = Ri.m[c];
+    for (int c = 0; c < 9; ++c) s.x.a.ximat[9 * b + c] = Ri.m[c];
   }
   WSYNC();
   if (lane < C::NJ) {          // joint anchors / axes in the world frame (frame of the body before the joint acts)
     int j = lane, jb = m.jnt_bodyid[j], jpar = m.body_parentid[jb];
     if (m.jnt_type[j] == JNT_FREE) {
-      st3(&s.xanchor[3 * j], ld3(&s.xpos[3 * jb])); st3(&s.xaxis[3 * j], v3(0, 0, 1));
+      st3(&s.x.a.xanchor[3 * j], ld3(&s.xpos[3 * jb])); st3(&s.x.a.xaxis[3 * j], v3(0, 0, 1));
     } else {
-      Q4 pq = ld4(&s.xquat[4 * jpar]);
+      Q4 pq = ld4(&s.x.a.xquat[4 * jpar]);
       Q4 qpre = qmul(pq, ld4(&m.body_quat[4 * jb]));
       V3 ppre = ld3(&s.xpos[3 * jpar]) + qrot(pq, ld3(&m.body_pos[3 * jb]));
-      st3(&s.xanchor[3 * j], ppre + qrot(qpre, ld3(&m.jnt_pos[3 * j])));
-      st3(&s.xaxis[3 * j], qrot(qpre, ld3(&m.jnt_axis[3 * j])));
+      st3(&s.x.a.xanchor[3 * j], ppre + qrot(qpre, ld3(&m.jnt_pos[3 * j])));
+      st3(&s.x.a.xaxis[3 * j], qrot(qpre, ld3(&m.jnt_axis[3 * j])));
     }
   }
   if (lane < C::NG) {
     int g = lane, gb = m.geom_bodyid[g];
-    Q4 gq = ld4(&s.xquat[4 * gb]);
-    st3(&s.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.xmat[9 * gb], ld3(&m.geom_pos[3 * g])));
+    Q4 gq = ld4(&s.x.a.xquat[4 * gb]);
+    st3(&s.x.a.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.x.a.xmat[9 * gb], ld3(&m.geom_pos[3 * g])));
     M33 Rg = q2m(qmul(gq, ld4(&m.geom_quat[4 * g])));
 #pragma unroll
-    for (int c = 0; c < 9; ++c) s.gmat[9 * g + c] = Rg.m[c];
+    for (int c = 0; c < 9; ++c) s.x.a.gmat[9 * g + c] = Rg.m[c];
   }
   if (lane < C::NS) {
     int sb = m.site_bodyid[lane];
-    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.xmat[9 * sb], ld3(&m.site_pos[3 * lane])));
+    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.x.a.xmat[9 * sb], ld3(&m.site_pos[3 * lane])));
   }
   WSYNC();
 }
@@ -307,18 +318,18 @@ __device__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
     while (mask) {
       int k = __builtin_ctz(mask); mask &= mask - 1;
       float mk = s.mass[k];
-      mm += mk; acc = acc + ld3(&s.xipos[3 * k]) * mk;
+      mm += mk; acc = acc + ld3(&s.x.a.xipos[3 * k]) * mk;
     }
-    V3 c = mm < RSR_MINVAL ? ld3(&s.xipos[3 * lane]) : acc * (1.0f / mm);
+    V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * lane]) : acc * (1.0f / mm);
     st3(&s.com[3 * lane], c);
   }
   WSYNC();
   if (lane < C::NB) {
     int b = lane;
-    const float* R = &s.ximat[9 * b];
-    V3 off = ld3(&s.xipos[3 * b]) - ld3(&s.com[3 * m.body_rootid[b]]);
+    const float* R = &s.x.a.ximat[9 * b];
+    V3 off = ld3(&s.x.a.xipos[3 * b]) - ld3(&s.com[3 * m.body_rootid[b]]);
     float I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2], ms = s.mass[b];
-    float* ci = &s.cinert[10 * b];
+    float* ci = &s.x.a.cinert[10 * b];
     ci[0] = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2] + ms * (off.y * off.y + off.z * off.z);
     ci[1] = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5] + ms * (off.x * off.x + off.z * off.z);
     ci[2] = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8] + ms * (off.x * off.x + off.y * off.y);
@@ -330,13 +341,13 @@ __device__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
   // cdof: lane = dof
   if (lane < C::NV) {
     int i = lane, j = m.dof_jntid[i], b = m.dof_bodyid[i], jt = m.jnt_type[j], k = i - m.jnt_dofadr[j];
-    V3 off = ld3(&s.com[3 * m.body_rootid[b]]) - ld3(&s.xanchor[3 * j]);
+    V3 off = ld3(&s.com[3 * m.body_rootid[b]]) - ld3(&s.x.a.xanchor[3 * j]);
     V3 ang, lin;
     if (jt == JNT_FREE) {
       if (k < 3) { ang = v3(0, 0, 0); lin = v3(k == 0, k == 1, k == 2); }
-      else { ang = col(&s.xmat[9 * b], k - 3); lin = cross(ang, off); }
-    } else if (jt == JNT_HINGE) { ang = ld3(&s.xaxis[3 * j]); lin = cross(ang, off); }
-    else { ang = v3(0, 0, 0); lin = ld3(&s.xaxis[3 * j]); }
+      else { ang = col(&s.x.a.xmat[9 * b], k - 3); lin = cross(ang, off); }
+    } else if (jt == JNT_HINGE) { ang = ld3(&s.x.a.xaxis[3 * j]); lin = cross(ang, off); }
+    else { ang = v3(0, 0, 0); lin = ld3(&s.x.a.xaxis[3 * j]); }
     st3(&s.cdof[6 * i], ang); st3(&s.cdof[6 * i + 3], lin);
   }
   for (int t = lane; t < C::NV * C::LD; t += 64) s.M[t] = 0.0f;
@@ -346,14 +357,14 @@ __device__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
     int b = t / 10, c = t - 10 * b;
     unsigned mask = b == 0 ? 0u : m.body_submask[b];
     float acc = 0;
-    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.cinert[10 * k + c]; }
-    s.crb[t] = acc;
+    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.x.a.cinert[10 * k + c]; }
+    s.x.a.crb[t] = acc;
   }
   WSYNC();
   if (lane < C::NV) {
     int i = lane;
     float f[6];
-    inert_mul(f, &s.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
+    inert_mul(f, &s.x.a.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
     unsigned mask = m.dof_ancmask[i];
     while (mask) {
       int j = __builtin_ctz(mask); mask &= mask - 1;
@@ -465,21 +476,40 @@ __device__ __forceinline__ void manifold_points(const float* x, const float* y, 
 
 struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; };
 
-// scr: 48 floats of per-lane LDS scratch (two ping-pong polygons of <=8 (x, y, depth) points)
-__device__ void plane_box(V3 pp, const float* pm, V3 bp, const float* bm, V3 size, float* scr, CPts& out) {
-  V3 n = col(pm, 2), ax = col(pm, 0), ay = col(pm, 1);
-  out.n = n; out.cnt = 0;
-  float* sup = scr; float* vx = scr + 8; float* vy = scr + 16;
+// A pair whose narrow phase found penetration and now needs LDS scratch for its manifold (24 floats for
+// plane-box vertex supports, 48 for the two ping-pong polygons of box-box clipping).  Everything the second
+// half needs is carried in registers, so only pairs that actually touch claim one of the NSLOT scratch slots.
+struct ClipJob {
+  int kind;                      // 0 = nothing pending, 1 = plane-box, 2 = box-box face contact
+  V3 o, nref, axu, axv;          // reference frame (box-box) / plane point, normal and in-plane axes (plane-box)
+  float hu, hv;                  // reference face half extents
+  float px[4], py[4], pd[4];     // incident face in the reference frame
+  bool flip;                     // reported normal = -nref (reference box is geom2)
+  V3 bp, size; const float* bm;  // plane-box: the box
+};
+
+__device__ __forceinline__ V3 box_vertex(const float* bm, V3 bp, V3 size, int v) {
+  V3 loc = v3((v & 4) ? size.x : -size.x, (v & 2) ? size.y : -size.y, (v & 1) ? size.z : -size.z);
+  return mulv(bm, loc) + bp;
+}
+
+__device__ void plane_box_sat(V3 pp, const float* pm, V3 bp, const float* bm, V3 size, CPts& out, ClipJob& job) {
+  V3 n = col(pm, 2);
+  out.n = n; out.cnt = 0; job.kind = 0;
   float smax = -1e30f;
-  for (int v = 0; v < 8; ++v) {
-    V3 loc = v3((v & 4) ? size.x : -size.x, (v & 2) ? size.y : -size.y, (v & 1) ? size.z : -size.z);
-    V3 w = mulv(bm, loc) + bp;
-    float sp = dot(pp - w, n);
-    sup[v] = sp; vx[v] = dot(w, ax); vy[v] = dot(w, ay);
-    smax = fmaxf(smax, sp);
-  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) smax = fmaxf(smax, dot(pp - box_vertex(bm, bp, size, v), n));
   if (!(smax > 0.0f)) return;
-  float thr = fmaxf(smax - 1e-3f, 0.0f);
+  job.kind = 1; job.o = pp; job.nref = n; job.axu = col(pm, 0); job.axv = col(pm, 1);
+  job.bp = bp; job.size = size; job.bm = bm; job.hu = smax;
+}
+__device__ void plane_box_clip(const ClipJob& job, float* scr, CPts& out) {
+  float* sup = scr; float* vx = scr + 8; float* vy = scr + 16;
+  for (int v = 0; v < 8; ++v) {
+    V3 w = box_vertex(job.bm, job.bp, job.size, v);
+    sup[v] = dot(job.o - w, job.nref); vx[v] = dot(w, job.axu); vy[v] = dot(w, job.axv);
+  }
+  float thr = fmaxf(job.hu - 1e-3f, 0.0f);
   unsigned mask = 0;
   for (int v = 0; v < 8; ++v) if (sup[v] > thr) mask |= 1u << v;
   int idx[4];
@@ -488,25 +518,23 @@ __device__ void plane_box(V3 pp, const float* pm, V3 bp, const float* bm, V3 siz
     bool dup = false;
     for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
     if (dup || !((mask >> idx[i]) & 1)) continue;
-    int v = idx[i];
-    float dist = -sup[v];
-    V3 loc = v3((v & 4) ? size.x : -size.x, (v & 2) ? size.y : -size.y, (v & 1) ? size.z : -size.z);
-    V3 w = mulv(bm, loc) + bp;
-    out.dist[out.cnt] = dist; out.pos[out.cnt] = w - n * (0.5f * dist); out.cnt++;
+    float dist = -sup[idx[i]];
+    out.dist[out.cnt] = dist; out.pos[out.cnt] = box_vertex(job.bm, job.bp, job.size, idx[i]) - job.nref * (0.5f * dist); out.cnt++;
   }
 }
 
-__device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, float* scr, CPts& out) {
-  out.cnt = 0;
-  float sa[3] = {sa_.x, sa_.y, sa_.z}, sb[3] = {sb_.x, sb_.y, sb_.z};
+// 15-axis SAT.  Separated pairs return nothing; edge-edge contacts are finished here; face contacts fill `job`.
+__device__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, CPts& out, ClipJob& job) {
+  out.cnt = 0; job.kind = 0;
+  const float sa[3] = {sa_.x, sa_.y, sa_.z}, sb[3] = {sb_.x, sb_.y, sb_.z};
   V3 dp = pb - pa;
+  V3 A[3] = {col(Ra, 0), col(Ra, 1), col(Ra, 2)}, B[3] = {col(Rb, 0), col(Rb, 1), col(Rb, 2)};
   float Cm[3][3], AC[3][3], t[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    V3 ai = col(Ra, i);
-    t[i] = dot(ai, dp);
+    t[i] = dot(A[i], dp);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { Cm[i][j] = dot(ai, col(Rb, j)); AC[i][j] = fabsf(Cm[i][j]) + 1e-6f; }
+    for (int j = 0; j < 3; ++j) { Cm[i][j] = dot(A[i], B[j]); AC[i][j] = fabsf(Cm[i][j]) + 1e-6f; }
   }
   float best_face = -1e30f; int face_code = -1; bool sep = false;
 #pragma unroll
@@ -523,7 +551,10 @@ __device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, 
     if (sv > best_face) { best_face = sv; face_code = 3 + j; }
   }
   if (sep) return;
-  float best_edge = -1e30f; int edge_i = -1, edge_j = -1;
+  // edge axes; the winning pair of edges is kept as vectors so that nothing is indexed dynamically afterwards
+  float best_edge = -1e30f; bool have_edge = false;
+  V3 eai = v3(0, 0, 0), ebj = v3(0, 0, 0); float ea_half = 0, eb_half = 0;
+  V3 ea_c = pa, eb_c = pb;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
@@ -531,59 +562,83 @@ __device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, 
     for (int j = 0; j < 3; ++j) {
       const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       float l2 = 1.0f - Cm[i][j] * Cm[i][j];
-      if (l2 < 1e-6f) continue;
       float ra = sa[i1] * AC[i2][j] + sa[i2] * AC[i1][j];
       float rb = sb[j1] * AC[i][j2] + sb[j2] * AC[i][j1];
       float tl = t[i2] * Cm[i1][j] - t[i1] * Cm[i2][j];
-      float sv = (fabsf(tl) - (ra + rb)) / sqrtf(l2);
-      sep |= sv > 0.0f;
-      if (sv > best_edge) { best_edge = sv; edge_i = i; edge_j = j; }
+      float sv = (fabsf(tl) - (ra + rb)) / sqrtf(fmaxf(l2, 1e-12f));
+      bool ok = !(l2 < 1e-6f);
+      sep |= ok && sv > 0.0f;
+      if (ok && sv > best_edge) {
+        best_edge = sv; have_edge = true; eai = A[i]; ebj = B[j]; ea_half = sa[i]; eb_half = sb[j];
+        V3 L = cross(A[i], B[j]);
+        if (dot(L, dp) < 0.0f) L = L * -1.0f;
+        ea_c = pa + A[i1] * ((dot(L, A[i1]) > 0 ? 1.0f : -1.0f) * sa[i1]) + A[i2] * ((dot(L, A[i2]) > 0 ? 1.0f : -1.0f) * sa[i2]);
+        eb_c = pb + B[j1] * ((dot(L, B[j1]) > 0 ? -1.0f : 1.0f) * sb[j1]) + B[j2] * ((dot(L, B[j2]) > 0 ? -1.0f : 1.0f) * sb[j2]);
+      }
     }
   }
   if (sep) return;
-  bool use_edge = (edge_i >= 0) && (best_edge > 0.95f * best_face + 1e-6f);
-  if (use_edge) {
-    V3 ai = col(Ra, edge_i), bj = col(Rb, edge_j);
-    V3 L = cross(ai, bj);
+  if (have_edge && (best_edge > 0.95f * best_face + 1e-6f)) {
+    V3 L = cross(eai, ebj);
     L = L * (1.0f / sqrtf(dot(L, L)));
     if (dot(L, dp) < 0.0f) L = L * -1.0f;
-    V3 ea = pa, eb = pb;
-    for (int k = 0; k < 3; ++k) {
-      if (k != edge_i) { V3 ak = col(Ra, k); ea = ea + ak * ((dot(L, ak) > 0 ? 1.0f : -1.0f) * sa[k]); }
-      if (k != edge_j) { V3 bk = col(Rb, k); eb = eb + bk * ((dot(L, bk) > 0 ? -1.0f : 1.0f) * sb[k]); }
-    }
-    V3 r = eb - ea;
-    float uab = dot(ai, bj), q1 = dot(ai, r), q2 = -dot(bj, r), den = 1.0f - uab * uab;
-    float sp = clampf((q1 + uab * q2) / den, -sa[edge_i], sa[edge_i]);
-    float up = clampf((uab * q1 + q2) / den, -sb[edge_j], sb[edge_j]);
-    V3 qa = ea + ai * sp, qb = eb + bj * up;
+    V3 r = eb_c - ea_c;
+    float uab = dot(eai, ebj), q1 = dot(eai, r), q2 = -dot(ebj, r), den = 1.0f - uab * uab;
+    float sp = clampf((q1 + uab * q2) / den, -ea_half, ea_half);
+    float up = clampf((uab * q1 + q2) / den, -eb_half, eb_half);
+    V3 qa = ea_c + eai * sp, qb = eb_c + ebj * up;
     float dist = dot(qb - qa, L);
     if (!(dist < 0.0f)) return;
     out.n = L; out.dist[0] = dist; out.pos[0] = (qa + qb) * 0.5f; out.cnt = 1;
     return;
   }
-  bool ref_is_a = face_code < 3;
-  int k = ref_is_a ? face_code : face_code - 3;
+  // face contact: reference box R, incident box Q; selections are done with compile-time indices + selects
+  const bool ref_is_a = face_code < 3;
+  const int k = ref_is_a ? face_code : face_code - 3;
   V3 pr = ref_is_a ? pa : pb, pq = ref_is_a ? pb : pa;
-  const float* Rr = ref_is_a ? Ra : Rb; const float* Rq = ref_is_a ? Rb : Ra;
-  const float* sr = ref_is_a ? sa : sb; const float* sq = ref_is_a ? sb : sa;
-  V3 nref = col(Rr, k);
-  if (dot(nref, pq - pr) < 0.0f) nref = nref * -1.0f;
-  int mq = 0; float bestd = -1.0f, dq[3];
-  for (int j = 0; j < 3; ++j) { dq[j] = dot(nref, col(Rq, j)); if (fabsf(dq[j]) > bestd) { bestd = fabsf(dq[j]); mq = j; } }
-  float sgn_q = dq[mq] > 0 ? -1.0f : 1.0f;
-  int uq = (mq + 1) % 3, vq = (mq + 2) % 3, ur = (k + 1) % 3, vr = (k + 2) % 3;
-  V3 axu = col(Rr, ur), axv = col(Rr, vr), o = pr + nref * sr[k];
-  V3 qm = col(Rq, mq), qu = col(Rq, uq), qv = col(Rq, vq);
-  // polygons in LDS scratch: buffer b, point i: scr[b*24 + i], +8, +16 for x, y, depth
-  const float su[4] = {1, -1, -1, 1}, sv4[4] = {1, 1, -1, -1};
-  for (int i = 0; i < 4; ++i) {
-    V3 w = pq + qm * (sgn_q * sq[mq]) + qu * (su[i] * sq[uq]) + qv * (sv4[i] * sq[vq]) - o;
-    scr[i] = dot(w, axu); scr[8 + i] = dot(w, axv); scr[16 + i] = -dot(w, nref);
+  V3 Rr[3], Rq[3]; float sr[3], sq[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    Rr[c] = ref_is_a ? A[c] : B[c]; Rq[c] = ref_is_a ? B[c] : A[c];
+    sr[c] = ref_is_a ? sa[c] : sb[c]; sq[c] = ref_is_a ? sb[c] : sa[c];
   }
+  V3 nref = k == 0 ? Rr[0] : (k == 1 ? Rr[1] : Rr[2]);
+  V3 axu = k == 0 ? Rr[1] : (k == 1 ? Rr[2] : Rr[0]);
+  V3 axv = k == 0 ? Rr[2] : (k == 1 ? Rr[0] : Rr[1]);
+  float hk = k == 0 ? sr[0] : (k == 1 ? sr[1] : sr[2]);
+  float hu = k == 0 ? sr[1] : (k == 1 ? sr[2] : sr[0]);
+  float hv = k == 0 ? sr[2] : (k == 1 ? sr[0] : sr[1]);
+  if (dot(nref, pq - pr) < 0.0f) nref = nref * -1.0f;
+  float d0 = dot(nref, Rq[0]), d1 = dot(nref, Rq[1]), d2 = dot(nref, Rq[2]);
+  int mq = 0; float bestd = fabsf(d0);
+  if (fabsf(d1) > bestd) { bestd = fabsf(d1); mq = 1; }
+  if (fabsf(d2) > bestd) { bestd = fabsf(d2); mq = 2; }
+  float dm = mq == 0 ? d0 : (mq == 1 ? d1 : d2);
+  float sgn_q = dm > 0 ? -1.0f : 1.0f;
+  V3 qm = mq == 0 ? Rq[0] : (mq == 1 ? Rq[1] : Rq[2]);
+  V3 qu = mq == 0 ? Rq[1] : (mq == 1 ? Rq[2] : Rq[0]);
+  V3 qv = mq == 0 ? Rq[2] : (mq == 1 ? Rq[0] : Rq[1]);
+  float sm = mq == 0 ? sq[0] : (mq == 1 ? sq[1] : sq[2]);
+  float su_ = mq == 0 ? sq[1] : (mq == 1 ? sq[2] : sq[0]);
+  float sv_ = mq == 0 ? sq[2] : (mq == 1 ? sq[0] : sq[1]);
+  V3 o = pr + nref * hk;
+  const float su[4] = {1, -1, -1, 1}, sv4[4] = {1, 1, -1, -1};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    V3 w = pq + qm * (sgn_q * sm) + qu * (su[i] * su_) + qv * (sv4[i] * sv_) - o;
+    job.px[i] = dot(w, axu); job.py[i] = dot(w, axv); job.pd[i] = -dot(w, nref);
+  }
+  job.kind = 2; job.o = o; job.nref = nref; job.axu = axu; job.axv = axv; job.hu = hu; job.hv = hv; job.flip = !ref_is_a;
+}
+
+// Sutherland-Hodgman of the incident face against the reference rectangle, then <=4 manifold points.
+// scr: 48 floats (two ping-pong polygons of <=8 (x, y, depth) points).
+__device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { scr[i] = job.px[i]; scr[8 + i] = job.py[i]; scr[16 + i] = job.pd[i]; }
   int np = 4, cur = 0;
   for (int side = 0; side < 4; ++side) {
-    float h = (side < 2) ? sr[ur] : sr[vr];
+    float h = (side < 2) ? job.hu : job.hv;
     float sg = (side & 1) ? -1.0f : 1.0f;
     float* P = scr + cur * 24; float* Qn = scr + (1 - cur) * 24;
     const float* cx = (side < 2) ? P : P + 8;
@@ -609,14 +664,14 @@ __device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, 
   if (!mask) return;
   int idx[4];
   manifold_points(P, P + 8, mask, np, idx);
-  out.n = ref_is_a ? nref : nref * -1.0f;
+  out.n = job.flip ? job.nref * -1.0f : job.nref;
   for (int i = 0; i < 4; ++i) {
     bool dup = false;
     for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
     if (dup || !((mask >> idx[i]) & 1)) continue;
     float x = P[idx[i]], y = P[8 + idx[i]], dep = P[16 + idx[i]];
     out.dist[out.cnt] = -dep;
-    out.pos[out.cnt] = o + axu * x + axv * y - nref * (0.5f * dep);
+    out.pos[out.cnt] = job.o + job.axu * x + job.axv * y - job.nref * (0.5f * dep);
     out.cnt++;
   }
 }
@@ -624,22 +679,32 @@ __device__ void box_box(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, 
 template <class C>
 __device__ void collision(const DModel& m, Smem<C>& s, int lane) {
   CPts pts; pts.cnt = 0;
-  float* scr = &s.J[lane * 48];            // per-lane clip scratch aliases the (not yet built) Jacobian
-  static_assert(C::NEFC * C::LD >= 64 * 48, "clip scratch does not fit in the Jacobian tile");
+  ClipJob job; job.kind = 0;
   float incl = 0.0f;
   if (lane < C::NP) {
     int p = lane, g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], kind = m.pair_kind[p];
     incl = m.pair_margin[p] - m.pair_gap[p];
-    V3 p1 = ld3(&s.gpos[3 * g1]), p2 = ld3(&s.gpos[3 * g2]);
-    if (kind == PAIR_PLANE_BOX) plane_box(p1, &s.gmat[9 * g1], p2, &s.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), scr, pts);
+    V3 p1 = ld3(&s.x.a.gpos[3 * g1]), p2 = ld3(&s.x.a.gpos[3 * g2]);
+    if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, &s.x.a.gmat[9 * g1], p2, &s.x.a.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), pts, job);
     else if (kind == PAIR_BOX_BOX)
-      box_box(p1, &s.gmat[9 * g1], ld3(&m.geom_size[3 * g1]), p2, &s.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), scr, pts);
+      box_box_sat(p1, &s.x.a.gmat[9 * g1], ld3(&m.geom_size[3 * g1]), p2, &s.x.a.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), pts, job);
     else if (kind == PAIR_PLANE_SPHERE) {
-      V3 n = col(&s.gmat[9 * g1], 2);
+      V3 n = col(&s.x.a.gmat[9 * g1], 2);
       float r = m.geom_size[3 * g2];
       float dist = dot(p2 - p1, n) - r;
       pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;
     }
+  }
+  // manifolds of the touching pairs, NSLOT at a time (usually one round: few pairs touch)
+  unsigned long long pend = __ballot(job.kind != 0);
+  while (pend) {
+    int rank = __popcll(pend & ((1ull << lane) - 1ull));
+    if (job.kind != 0 && rank < NSLOT) {
+      float* scr = &s.x.a.clip[rank * 48];
+      if (job.kind == 1) plane_box_clip(job, scr, pts); else box_box_clip(job, scr, pts);
+      job.kind = 0;
+    }
+    pend = __ballot(job.kind != 0);
   }
   // keep penetrating contacts only (result-neutral culling), compact in pair order
   int keep = 0;
@@ -648,7 +713,6 @@ __device__ void collision(const DModel& m, Smem<C>& s, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl_scan, o); if (lane >= o) incl_scan += v; }
   int base = incl_scan - keep, total = __shfl(incl_scan, 63);
-  WSYNC();                                  // all lanes are done with the clip scratch
   int w = base;
   for (int i = 0; i < pts.cnt; ++i) {
     if (!(pts.dist[i] - incl < 0.0f)) continue;
@@ -683,7 +747,7 @@ __device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel
       for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
     }
 #pragma unroll
-    for (int c = 0; c < 6; ++c) s.cvel[6 * lane + c] = v[c];
+    for (int c = 0; c < 6; ++c) s.x.a.cvel[6 * lane + c] = v[c];
   }
   // cdof_dot[i] = (velocity of the chain before dof i) x cdof[i]
   if (lane < C::NV) {
@@ -700,7 +764,7 @@ __device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel
     float o[6];
     motion_cross(o, v, &s.cdof[6 * lane]);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) s.cdofdot[6 * lane + c] = free_trans ? 0.0f : o[c];
+    for (int c = 0; c < 6; ++c) s.x.a.cdofdot[6 * lane + c] = free_trans ? 0.0f : o[c];
   }
   WSYNC();
   // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)
@@ -711,23 +775,23 @@ __device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel
       int i = __builtin_ctz(mask); mask &= mask - 1;
       float qd = s.qvel[i];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a[c] += s.cdofdot[6 * i + c] * qd;
+      for (int c = 0; c < 6; ++c) a[c] += s.x.a.cdofdot[6 * i + c] * qd;
     }
     float f1[6], f2[6];
-    inert_mul(f1, &s.cinert[10 * lane], a);
-    inert_mul(f2, &s.cinert[10 * lane], &s.cvel[6 * lane]);
-    V3 va = ld3(&s.cvel[6 * lane]), vl = ld3(&s.cvel[6 * lane + 3]), fa = ld3(f2), fl = ld3(f2 + 3);
+    inert_mul(f1, &s.x.a.cinert[10 * lane], a);
+    inert_mul(f2, &s.x.a.cinert[10 * lane], &s.x.a.cvel[6 * lane]);
+    V3 va = ld3(&s.x.a.cvel[6 * lane]), vl = ld3(&s.x.a.cvel[6 * lane + 3]), fa = ld3(f2), fl = ld3(f2 + 3);
     V3 ta = cross(va, fa) + cross(vl, fl), tl = cross(va, fl);
-    s.cfrc[6 * lane + 0] = f1[0] + ta.x; s.cfrc[6 * lane + 1] = f1[1] + ta.y; s.cfrc[6 * lane + 2] = f1[2] + ta.z;
-    s.cfrc[6 * lane + 3] = f1[3] + tl.x; s.cfrc[6 * lane + 4] = f1[4] + tl.y; s.cfrc[6 * lane + 5] = f1[5] + tl.z;
+    s.x.a.cfrc[6 * lane + 0] = f1[0] + ta.x; s.x.a.cfrc[6 * lane + 1] = f1[1] + ta.y; s.x.a.cfrc[6 * lane + 2] = f1[2] + ta.z;
+    s.x.a.cfrc[6 * lane + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * lane + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * lane + 5] = f1[5] + tl.z;
   }
   WSYNC();
   for (int t = lane; t < C::NB * 6; t += 64) {
     int b = t / 6, c = t - 6 * b;
     unsigned mask = m.body_submask[b];
     float acc = 0;
-    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.cfrc[6 * k + c]; }
-    s.cfrcsum[t] = acc;
+    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.x.a.cfrc[6 * k + c]; }
+    s.x.a.cfrcsum[t] = acc;
   }
   WSYNC();
   float smooth = 0.0f;
@@ -735,7 +799,7 @@ __device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel
     int i = lane, b = m.dof_bodyid[i];
     float bias = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) bias += s.cdof[6 * i + c] * s.cfrcsum[6 * b + c];
+    for (int c = 0; c < 6; ++c) bias += s.cdof[6 * i + c] * s.x.a.cfrcsum[6 * b + c];
     float passive = -s.damp[i] * qvel_i;
     // actuation: joint transmissions; lanes scan the (few) actuators for their dof
     float act = 0;
@@ -807,22 +871,23 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
   const int nefc = r_con + 6 * ncon;
   WSYNC();
   // zero the sparse rows, then poke their entries
-  for (int t = lane; t < r_con * LD; t += 64) s.J[t] = 0.0f;
+  for (int t = lane; t < r_con * LD; t += 64) s.x.b.J[t] = 0.0f;
+  if (lane < LD) s.x.b.J[C::NEFC * LD + lane] = 0.0f;       // null row (phase A used this memory)
   WSYNC();
   if (lane < C::NEQ && m.eq_active0[lane]) {
     int e = lane, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
     float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
     const float* dt = &m.eq_data[5 * e];
     float deriv = dt[1] + dif * (2.0f * dt[2] + dif * (3.0f * dt[3] + dif * 4.0f * dt[4]));
-    if (j2 >= 0) s.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
-    s.J[e * LD + m.jnt_dofadr[j1]] = 1.0f;
+    if (j2 >= 0) s.x.b.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
+    s.x.b.J[e * LD + m.jnt_dofadr[j1]] = 1.0f;
   }
-  if (lane < C::NF) s.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f;
+  if (lane < C::NF) s.x.b.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f;
   if (lane < nl) {
     int j = s.lim_jnt[lane];
     float q = s.qpos[m.jnt_qposadr[j]];
     float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
-    s.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
+    s.x.b.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
   }
   // contact rows: item (contact c, dof i) fills the six pyramid edges
   for (int t = lane; t < ncon * C::NV; t += 64) {
@@ -840,7 +905,7 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
     float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]), f1 = fmaxf(s.fric[3 * g1 + 1], s.fric[3 * g2 + 1]);
     int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
     if (pr1 != pr2) { int gw = pr1 > pr2 ? g1 : g2; f0 = s.fric[3 * gw]; f1 = s.fric[3 * gw + 1]; }
-    float* Jr = &s.J[(r_con + 6 * c) * LD + i];
+    float* Jr = &s.x.b.J[(r_con + 6 * c) * LD + i];
     Jr[0 * LD] = dn + f0 * d1; Jr[1 * LD] = dn - f0 * d1;
     Jr[2 * LD] = dn + f0 * d2; Jr[3 * LD] = dn - f0 * d2;
     Jr[4 * LD] = dn + f1 * dr; Jr[5 * LD] = dn - f1 * dr;
@@ -882,7 +947,7 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
       }
       float vel = 0;
 #pragma unroll
-      for (int i = 0; i < C::NV; ++i) vel += s.J[r * LD + i] * s.qvel[i];
+      for (int i = 0; i < C::NV; ++i) vel += s.x.b.J[r * LD + i] * s.qvel[i];
       float k, b, imp;
       kbi(m, sr0, sr1, si, pos, k, b, imp);
       float R = fmaxf(invw * (1.0f - imp) / imp, RSR_MINVAL);

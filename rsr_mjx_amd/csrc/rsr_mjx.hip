@@ -57,8 +57,7 @@ __device__ __forceinline__ float uniform_from_bits(uint32_t b, float lo, float h
 // ---------------------------------------------------------------- record I/O
 template <class C>
 __device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, int e, int lane) {
-  if (lane < C::LD) s.J[C::NEFC * C::LD + lane] = 0.0f;      // the null row and its zero weight
-  if (lane < 4) s.rw[C::NEFC + lane] = 0.0f;
+  if (lane < 4) s.rw[C::NEFC + lane] = 0.0f;                 // zero weight of the null row
   for (int t = lane; t < C::NG * 3; t += 64) s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + t] : m.geom_friction[t];
   if (lane < C::NB) s.mass[lane] = a.dr_body_mass ? a.dr_body_mass[(size_t)e * C::NB + lane] : m.body_mass[lane];
   if (lane < C::NV) {
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs 
 
 // ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
 template <class C>
-__global__ __launch_bounds__(64, 2) void step_kernel(DModel m, Layout L, StepArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(168))) void step_kernel(DModel m, Layout L, StepArgs a) {
   __shared__ Smem<C> s;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;

@@ -24,7 +24,7 @@ __device__ __forceinline__ void jdot(const Smem<C>& s, int lane, int nefc, float
     if (64 * ch < nefc) {                     // wave-uniform: chunks past the last row cost nothing
       int rr_ = r < nefc ? r : C::NEFC;       // padding lanes read the null row
 #pragma unroll
-      for (int i = 0; i < C::NV; ++i) acc += s.J[rr_ * C::LD + i] * vb[i];
+      for (int i = 0; i < C::NV; ++i) acc += s.x.b.J[rr_ * C::LD + i] * vb[i];
     }
     out[ch] = acc;
   }
@@ -142,8 +142,8 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, const 
   float acc0 = 0, acc1 = 0;
   for (int k = 0; k < n; k += 4) {
     int r0 = s.rlist[k], r1 = s.rlist[k + 1], r2 = s.rlist[k + 2], r3 = s.rlist[k + 3];
-    acc0 += s.J[r0 * C::LD + col] * s.rw[r0]; acc1 += s.J[r1 * C::LD + col] * s.rw[r1];
-    acc0 += s.J[r2 * C::LD + col] * s.rw[r2]; acc1 += s.J[r3 * C::LD + col] * s.rw[r3];
+    acc0 += s.x.b.J[r0 * C::LD + col] * s.rw[r0]; acc1 += s.x.b.J[r1 * C::LD + col] * s.rw[r1];
+    acc0 += s.x.b.J[r2 * C::LD + col] * s.rw[r2]; acc1 += s.x.b.J[r3 * C::LD + col] * s.rw[r3];
   }
   return lane < C::NV ? acc0 + acc1 : 0.0f;
 }
@@ -167,7 +167,7 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int r = s.rlist[k + u];
-      const float* Jr = &s.J[r * C::LD];
+      const float* Jr = &s.x.b.J[r * C::LD];
       float w = s.rw[r];
       float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
       h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
@@ -322,11 +322,7 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) Mrow[j] = lane < C::NV ? s.M[lane * C::LD + j] : 0.0f;
   PROF(PS_COMCRB)
-  collision<C>(m, s, lane);
-  PROF(PS_COLL)
-  RowRegs rr[C::NCHUNK];
-  int nefc = make_constraint<C>(m, s, lane, rr);
-  PROF(PS_ROWS)
+  // velocity stage first: its scratch and the frames die before the Jacobian claims the shared LDS region
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
   float fs = smooth_forces<C>(m, s, lane, qvel_i, 0.0f);
   PROF(PS_SMOOTH)
@@ -336,8 +332,13 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
   for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] : 0.0f;
   chol_factor<C>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, fs, lane) : 0.0f;
-  out.fsmooth = fs; out.nefc = nefc;
   PROF(PS_CHOLM)
+  collision<C>(m, s, lane);
+  PROF(PS_COLL)
+  RowRegs rr[C::NCHUNK];
+  int nefc = make_constraint<C>(m, s, lane, rr);
+  PROF(PS_ROWS)
+  out.fsmooth = fs; out.nefc = nefc;
   solve<C>(m, s, lane, nefc, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
@@ -346,7 +347,6 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
       dbg[4] = (float)out.st.niter; dbg[5] = (float)out.st.ls_total; dbg[6] = (float)s.nlim_act; dbg[7] = (float)s.ncon_drop;
     }
     for (int t = lane; t < C::NB * 3; t += 64) dbg[16 + t] = s.xpos[t];
-    for (int t = lane; t < C::NB * 4; t += 64) dbg[64 + t] = s.xquat[t];
     for (int t = lane; t < C::NV * C::NV; t += 64) dbg[128 + t] = s.M[(t / C::NV) * C::LD + (t % C::NV)];
     if (lane < C::NV) {
       dbg[736 + lane] = fs; dbg[768 + lane] = a0; dbg[800 + lane] = out.qacc; dbg[832 + lane] = out.qfc;
@@ -361,13 +361,9 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
       int r = lane + 64 * ch;
       if (r < nefc && r < 256) { dbg[1152 + r] = rr[ch].aref; dbg[1408 + r] = rr[ch].D; }
     }
-    for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) dbg[2048 + t] = s.J[(t / C::NV) * C::LD + (t % C::NV)];
-    for (int t = lane; t < C::NG * 3; t += 64) dbg[6400 + t] = s.gpos[t];
+    for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) dbg[2048 + t] = s.x.b.J[(t / C::NV) * C::LD + (t % C::NV)];
     for (int t = lane; t < C::NV * 6; t += 64) dbg[6528 + t] = s.cdof[t];
-    for (int t = lane; t < C::NB * 10; t += 64) dbg[6656 + t] = s.cinert[t];
     for (int t = lane; t < C::NB * 3; t += 64) dbg[6800 + t] = s.com[t];
-    for (int t = lane; t < C::NB * 6; t += 64) dbg[6848 + t] = s.cvel[t];
-    for (int t = lane; t < C::NV * 6; t += 64) dbg[6944 + t] = s.cdofdot[t];
   }
 }
 
