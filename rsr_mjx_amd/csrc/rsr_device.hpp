@@ -82,8 +82,14 @@ struct Dims {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
   static constexpr int LD = NV_ + 1;                        // padded row stride: conflict-free row and column reads
-  static constexpr int NEFC = NEQ_ + NF_ + NL_ + 6 * NCON_;   // constraint-row capacity
+  static constexpr int NEFC = NEQ_ + NF_ + NL_ + 6 * NCON_;   // constraint-row capacity (pyramid rows)
   static constexpr int NCHUNK = (NEFC + 63) / 64;           // rows per lane
+  // The Jacobian is stored as BASE rows: the sparse rows as they are, and per contact the four contact-frame
+  // rows (normal, tangent 1, tangent 2, torsion); the six pyramid edges are +-mu combinations of those.
+  static constexpr int NBC = 4;
+  static constexpr int NSP = NEQ_ + NF_ + NL_;
+  static constexpr int NBASE = NSP + NBC * NCON_;
+  static constexpr int NCHB = (NBASE + 63) / 64;
 };
 
 // ---- tiny vector helpers ----
@@ -192,7 +198,7 @@ struct PhaseA {
 };
 template <class C>
 struct PhaseB {
-  float J[(C::NEFC + 1) * C::LD];                      // row NEFC is the null row (zero weight) padding row lists
+  float J[(C::NBASE + 1) * C::LD];                     // base rows; row NBASE is the null row padding row lists
 };
 template <class C>
 struct Smem {
@@ -207,8 +213,12 @@ struct Smem {
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int lim_jnt[C::NL > 0 ? C::NL : 1];
-  float rw[C::NEFC + 4];                               // per-row weight D*active (Hessian) or force (J^T f)
-  int rlist[C::NEFC + 4];                              // compacted indices of the rows with non-zero weight
+  float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
+  float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
+  float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction
+  float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian
+  int rlist[C::NBASE + 4];                             // compacted base rows / contacts with non-zero weight
+  int clist[C::NCON + 4];
   union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
 
@@ -827,7 +837,9 @@ __device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel
 // stage 5: constraint rows.  Row order: equality, dof friction, active limits, contacts (6 pyramid
 // edges each).  J lives in LDS; the per-row scalars are returned in lane registers (row = lane + 64*c).
 // =====================================================================================
-struct RowRegs { float aref, D, R, floss; };   // floss < 0 marks "not a friction row"; D = 0 marks padding
+// per pyramid row: floss < 0 marks "not a friction row"; D = 0 marks padding.
+// Row = base[bn] + mu * base[bk] (mu = 0 and bk = bn for the sparse rows).
+struct RowRegs { float aref, D, R, floss, mu; int bn, bk; };
 
 __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const float* si, float pos, float& k, float& b, float& imp) {
   float timeconst = sr0, dampratio = sr1;
@@ -852,8 +864,11 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
   if (x > 1.0f) imp = dmax;
 }
 
+// Returns nefc; rr[] holds the per-row scalars except the velocity part of aref: the caller finishes
+// aref -= bcoef * (J.qvel) once the base rows are in LDS (it owns the J.v machinery).
 template <class C>
-__device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK]) {
+__device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
+                               int& nbase_out) {
   constexpr int LD = C::LD;
   // active joint limits, compacted in joint order
   int lim_active = 0;
@@ -872,7 +887,9 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
   WSYNC();
   // zero the sparse rows, then poke their entries
   for (int t = lane; t < r_con * LD; t += 64) s.x.b.J[t] = 0.0f;
-  if (lane < LD) s.x.b.J[C::NEFC * LD + lane] = 0.0f;       // null row (phase A used this memory)
+  if (lane < LD) s.x.b.J[C::NBASE * LD + lane] = 0.0f;      // null row (phase A used this memory)
+  if (lane < 4) { s.bval[C::NBASE + lane] = 0.0f; s.bmu[C::NBASE + lane] = 0.0f; }
+  for (int t = lane; t < r_con; t += 64) s.bmu[t] = 0.0f;
   WSYNC();
   if (lane < C::NEQ && m.eq_active0[lane]) {
     int e = lane, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
@@ -889,7 +906,7 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
     float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
     s.x.b.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
   }
-  // contact rows: item (contact c, dof i) fills the six pyramid edges
+  // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
     int p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
@@ -901,23 +918,27 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
     V3 o1 = pos - ld3(&s.com[3 * m.body_rootid[b1]]), o2 = pos - ld3(&s.com[3 * m.body_rootid[b2]]);
     V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
     V3 jr = ang * (in2 - in1);
-    float dn = dot(nn, jp), d1 = dot(t1, jp), d2 = dot(t2, jp), dr = dot(nn, jr);
+    float* Jr = &s.x.b.J[(r_con + C::NBC * c) * LD + i];
+    Jr[0 * LD] = dot(nn, jp); Jr[1 * LD] = dot(t1, jp); Jr[2 * LD] = dot(t2, jp); Jr[3 * LD] = dot(nn, jr);
+  }
+  // friction coefficient of each contact base row (normal: unused)
+  for (int t = lane; t < ncon * C::NBC; t += 64) {
+    int c = t / C::NBC, k = t - c * C::NBC;
+    int p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]), f1 = fmaxf(s.fric[3 * g1 + 1], s.fric[3 * g2 + 1]);
     int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
     if (pr1 != pr2) { int gw = pr1 > pr2 ? g1 : g2; f0 = s.fric[3 * gw]; f1 = s.fric[3 * gw + 1]; }
-    float* Jr = &s.x.b.J[(r_con + 6 * c) * LD + i];
-    Jr[0 * LD] = dn + f0 * d1; Jr[1 * LD] = dn - f0 * d1;
-    Jr[2 * LD] = dn + f0 * d2; Jr[3 * LD] = dn - f0 * d2;
-    Jr[4 * LD] = dn + f1 * dr; Jr[5 * LD] = dn - f1 * dr;
+    s.bmu[r_con + t] = k == 0 ? 0.0f : (k == 3 ? f1 : f0);
   }
   WSYNC();
-  // per-row reference acceleration, regulariser
+  // per-row regulariser and reference acceleration (the velocity term J.qvel is added by the caller)
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
     int r = lane + 64 * ch;
-    RowRegs o{0.0f, 0.0f, 1.0f, -1.0f};
+    RowRegs o{0.0f, 0.0f, 1.0f, -1.0f, 0.0f, C::NBASE, C::NBASE};
     if (r < nefc) {
       float pos = 0, invw = 0, sr0, sr1, fl = -1.0f; const float* si;
+      o.bn = r; o.bk = r;
       if (r < r_fric) {
         int e = r, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
         float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
@@ -936,26 +957,29 @@ __device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&
         pos = fminf(q - m.jnt_range[2 * j], m.jnt_range[2 * j + 1] - q) - m.jnt_margin[j];
         invw = m.dof_invweight0[m.jnt_dofadr[j]]; sr0 = m.jnt_solref[2 * j]; sr1 = m.jnt_solref[2 * j + 1]; si = &m.jnt_solimp[5 * j];
       } else {
-        int c = (r - r_con) / 6, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+        int c = (r - r_con) / 6, e = (r - r_con) - 6 * c, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
         pos = s.cdist[c] - (m.pair_margin[p] - m.pair_gap[p]);
-        float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]);
-        int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
-        if (pr1 != pr2) f0 = s.fric[3 * (pr1 > pr2 ? g1 : g2)];
+        o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
+        float f0 = s.bmu[o.bn + 1];
+        o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
         float tw = m.body_invweight0[2 * m.geom_bodyid[g1]] + m.body_invweight0[2 * m.geom_bodyid[g2]];
         invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / m.impratio;
         sr0 = m.pair_solref[2 * p]; sr1 = m.pair_solref[2 * p + 1]; si = &m.pair_solimp[5 * p];
       }
-      float vel = 0;
-#pragma unroll
-      for (int i = 0; i < C::NV; ++i) vel += s.x.b.J[r * LD + i] * s.qvel[i];
       float k, b, imp;
       kbi(m, sr0, sr1, si, pos, k, b, imp);
       float R = fmaxf(invw * (1.0f - imp) / imp, RSR_MINVAL);
-      o.R = R; o.D = 1.0f / R; o.aref = -b * vel - k * imp * pos; o.floss = fl;
+      o.R = R; o.D = 1.0f / R; o.floss = fl;
+      o.aref = -k * imp * pos;        // the caller subtracts b * (J.qvel)
+      rr[ch] = o;
+      bcoef[ch] = b;
+    } else {
+      rr[ch] = o;
+      bcoef[ch] = 0.0f;
     }
-    rr[ch] = o;
   }
   if (lane == 0) s.nlim_act = nl;
+  nbase_out = r_con + C::NBC * ncon;
   return nefc;
 }
 

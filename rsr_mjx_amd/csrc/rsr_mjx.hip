@@ -90,7 +90,8 @@ __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane
 
 // ---------------------------------------------------------------- reset kernel (cube_env.py:95-143 + wrappers)
 template <class C>
-__global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs a) {
+__global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
   __shared__ Smem<C> s;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(64) void reset_kernel(DModel m, Layout L, StepArgs 
 
 // ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
 template <class C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(168))) void step_kernel(DModel m, Layout L, StepArgs a) {
+__global__ __launch_bounds__(64) void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
   __shared__ Smem<C> s;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
@@ -322,7 +324,8 @@ struct rsr_batch {
   int n, device;
   float* state; bool owns_state;
   char* dblob;
-  DModel dm;
+  DModel dm;            // host copy of the device model view
+  DModel* dmodel;       // the same struct in device memory (kernels take a pointer: fewer live SGPRs)
   const float *dr_fric, *dr_mass, *dr_damp, *dr_floss;
   float* debug;
   hipEvent_t ev0, ev1; bool timing; int launches;
@@ -445,6 +448,9 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   HIPCHK(hipMemcpy(b->dblob, m->blob.data(), m->blob.size(), hipMemcpyHostToDevice));
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return rc; }
+  b->dmodel = nullptr;
+  if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
+  HIPCHK(hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice));
   *out = b;
   return RSR_OK;
 }
@@ -455,6 +461,7 @@ extern "C" void rsr_batch_destroy(rsr_batch* b) {
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->dblob) (void)hipFree(b->dblob);
+  if (b->dmodel) (void)hipFree(b->dmodel);
   if (b->owns_state && b->state) (void)hipFree(b->state);
   delete b;
 }
@@ -485,7 +492,7 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.keys = keys;
-  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dm,
+  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dmodel,
                      b->model->layout, a);
   HIPCHK(hipGetLastError());
   return RSR_OK;
@@ -496,7 +503,7 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.action = action;
-  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dm,
+  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dmodel,
                      b->model->layout, a);
   HIPCHK(hipGetLastError());
   if (b->timing) b->launches++;

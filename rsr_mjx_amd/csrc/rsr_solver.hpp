@@ -11,22 +11,30 @@ namespace rsr {
 template <class C>
 struct DofRegs { float qacc, Ma, grad, search, mv, qfc; };
 
-// J * v for the rows owned by this lane (v: per-dof vector, lane i holds v_i)
+// J * v for the pyramid rows owned by this lane (v: per-dof vector, lane i holds v_i): dot products with the
+// base rows (lane = base row), published through LDS, then combined as base[bn] + mu * base[bk].
 template <class C>
-__device__ __forceinline__ void jdot(const Smem<C>& s, int lane, int nefc, float v, float (&out)[C::NCHUNK]) {
+__device__ __forceinline__ void jdot(Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK], float v,
+                                     float (&out)[C::NCHUNK]) {
   float vb[C::NV];
 #pragma unroll
   for (int i = 0; i < C::NV; ++i) vb[i] = rdlane(v, i);
+  WSYNC();
+#pragma unroll
+  for (int ch = 0; ch < C::NCHB; ++ch) {
+    if (64 * ch >= nbase) continue;             // wave-uniform
+    int b = lane + 64 * ch, bb = b < nbase ? b : C::NBASE;
+    float acc = 0;
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) acc += s.x.b.J[bb * C::LD + i] * vb[i];
+    if (b < nbase) s.bval[b] = acc;
+  }
+  WSYNC();
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
-    int r = lane + 64 * ch;
-    float acc = 0;
-    if (64 * ch < nefc) {                     // wave-uniform: chunks past the last row cost nothing
-      int rr_ = r < nefc ? r : C::NEFC;       // padding lanes read the null row
-#pragma unroll
-      for (int i = 0; i < C::NV; ++i) acc += s.x.b.J[rr_ * C::LD + i] * vb[i];
-    }
-    out[ch] = acc;
+    out[ch] = 0.0f;
+    if (64 * ch >= nefc) continue;
+    out[ch] = s.bval[rr[ch].bn] + rr[ch].mu * s.bval[rr[ch].bk];
   }
 }
 
@@ -114,48 +122,87 @@ __device__ __forceinline__ LSPoint ls_point(int lane, int nefc, float alpha, con
   return o[0];
 }
 
-// Publishes per-row weights to LDS and compacts the indices of the non-zero ones (ballot + prefix popcount);
-// the list is padded with the null row so that consumers can walk it four rows at a time.
-template <class C>
-__device__ __forceinline__ int publish_rows(Smem<C>& s, int lane, int nefc, const float (&w)[C::NCHUNK]) {
-  WSYNC();
+// compacts the indices r in [0, n) whose flag is set into list[], padded with `pad` to a multiple of four
+template <int NCH>
+__device__ __forceinline__ int compact_list(int* list, int lane, const bool (&on)[NCH], int pad) {
   int base = 0;
 #pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) {
-    int r = lane + 64 * ch;
-    bool on = r < nefc && w[ch] != 0.0f;
-    if (r < nefc) s.rw[r] = w[ch];
-    unsigned long long mask = __ballot(on);
-    if (on) s.rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = r;
+  for (int ch = 0; ch < NCH; ++ch) {
+    unsigned long long mask = __ballot(on[ch]);
+    if (on[ch]) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = lane + 64 * ch;
     base += __popcll(mask);
   }
-  if (lane < 4) s.rlist[base + lane] = C::NEFC;
-  WSYNC();
+  if (lane < 4) list[base + lane] = pad;
   return base;
 }
 
-// qfrc_constraint = J^T force over the rows with non-zero force, four rows per trip
+// qfrc_constraint = J^T force.  The pyramid forces are folded onto the base rows first
+// (normal: sum of the six edges; direction k: mu_k * (f_k+ - f_k-)), then J_base^T g, four base rows per trip.
 template <class C>
-__device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, const float (&force)[C::NCHUNK]) {
-  const int n = publish_rows<C>(s, lane, nefc, force);
+__device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nbase, const float (&force)[C::NCHUNK]) {
+  constexpr int r_con = 0;   // (placeholder to keep the expression below readable)
+  (void)r_con;
+  WSYNC();
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = force[ch]; }
+  WSYNC();
+  const int rcon = nefc - 6 * s.ncon;           // first contact row (pyramid and base numbering agree below it)
+  bool on[C::NCHB];
+#pragma unroll
+  for (int ch = 0; ch < C::NCHB; ++ch) {
+    int b = lane + 64 * ch;
+    float g = 0.0f;
+    if (b < rcon) g = s.rw[b];
+    else if (b < nbase) {
+      int c = (b - rcon) >> 2, k = (b - rcon) & 3, r0 = rcon + 6 * c;
+      if (k == 0) g = ((s.rw[r0] + s.rw[r0 + 1]) + (s.rw[r0 + 2] + s.rw[r0 + 3])) + (s.rw[r0 + 4] + s.rw[r0 + 5]);
+      else g = s.bmu[b] * (s.rw[r0 + 2 * (k - 1)] - s.rw[r0 + 2 * (k - 1) + 1]);
+    }
+    if (b < nbase) s.bval[b] = g;
+    on[ch] = b < nbase && g != 0.0f;
+  }
+  const int n = compact_list<C::NCHB>(s.rlist, lane, on, C::NBASE);
+  WSYNC();
   const int col = lane < C::NV ? lane : 0;
   float acc0 = 0, acc1 = 0;
   for (int k = 0; k < n; k += 4) {
     int r0 = s.rlist[k], r1 = s.rlist[k + 1], r2 = s.rlist[k + 2], r3 = s.rlist[k + 3];
-    acc0 += s.x.b.J[r0 * C::LD + col] * s.rw[r0]; acc1 += s.x.b.J[r1 * C::LD + col] * s.rw[r1];
-    acc0 += s.x.b.J[r2 * C::LD + col] * s.rw[r2]; acc1 += s.x.b.J[r3 * C::LD + col] * s.rw[r3];
+    acc0 += s.x.b.J[r0 * C::LD + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LD + col] * s.bval[r1];
+    acc0 += s.x.b.J[r2 * C::LD + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LD + col] * s.bval[r3];
   }
   return lane < C::NV ? acc0 + acc1 : 0.0f;
 }
 
 // H = M + J^T diag(hw) J as 2x2 blocks (lane = block of the lower triangle), then factor.
+// Sparse rows are rank-1 updates; a contact adds B^T W B with B its four base rows and W the arrow matrix
+//   W_nn = sum hw,  W_nk = mu_k (hw_k+ - hw_k-),  W_kk = mu_k^2 (hw_k+ + hw_k-)   (k = tangent 1, tangent 2, torsion).
 template <class C>
-__device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, const float (&hw)[C::NCHUNK],
+__device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
                                                float (&a)[C::NV], float (&lt)[C::NV]) {
   constexpr int NBLK = (C::NV + 1) / 2;
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
-  const int n = publish_rows<C>(s, lane, nefc, hw);
+  static_assert(C::NSP <= 64 && C::NCON <= 64, "one lane per sparse row / contact");
+  WSYNC();
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = hw[ch]; }
+  WSYNC();
+  const int ncon = s.ncon, rcon = nefc - 6 * ncon;
+  bool son[1] = {lane < rcon && s.rw[lane < rcon ? lane : 0] != 0.0f};
+  const int nsp = compact_list<1>(s.rlist, lane, son, C::NBASE);
+  bool con[1] = {false};
+  if (lane < ncon) {
+    int r0 = rcon + 6 * lane, b0 = rcon + 4 * lane;
+    float h0 = s.rw[r0], h1 = s.rw[r0 + 1], h2 = s.rw[r0 + 2], h3 = s.rw[r0 + 3], h4 = s.rw[r0 + 4], h5 = s.rw[r0 + 5];
+    float m1 = s.bmu[b0 + 1], m2 = s.bmu[b0 + 2], m3 = s.bmu[b0 + 3];
+    float* w = &s.wc[8 * lane];
+    w[0] = ((h0 + h1) + (h2 + h3)) + (h4 + h5);
+    w[1] = m1 * (h0 - h1); w[2] = m2 * (h2 - h3); w[3] = m3 * (h4 - h5);
+    w[4] = m1 * m1 * (h0 + h1); w[5] = m2 * m2 * (h2 + h3); w[6] = m3 * m3 * (h4 + h5);
+    con[0] = w[0] != 0.0f;
+  }
+  const int nc = compact_list<1>(s.clist, lane, con, -1);
+  WSYNC();
   int bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
   int bj = lane - bi * (bi + 1) / 2;
@@ -163,15 +210,34 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, c
   int i0 = blk ? 2 * bi : 0, j0 = blk ? 2 * bj : 0;
   float h00 = s.M[i0 * C::LD + j0], h01 = s.M[i0 * C::LD + j0 + 1];
   float h10 = s.M[(i0 + 1) * C::LD + j0], h11 = s.M[(i0 + 1) * C::LD + j0 + 1];
-  for (int k = 0; k < n; k += 4) {
+  for (int k = 0; k < nsp; k += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       int r = s.rlist[k + u];
       const float* Jr = &s.x.b.J[r * C::LD];
-      float w = s.rw[r];
+      float w = r < C::NBASE ? s.rw[r] : 0.0f;
       float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
       h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
     }
+  }
+  for (int k = 0; k < nc; ++k) {
+    int c = s.clist[k];
+    const float* B = &s.x.b.J[(rcon + 4 * c) * C::LD];
+    const float* w = &s.wc[8 * c];
+    float wnn = w[0], wn1 = w[1], wn2 = w[2], wn3 = w[3], w11 = w[4], w22 = w[5], w33 = w[6];
+    float ni0 = B[i0], ni1 = B[i0 + 1], nj0 = B[j0], nj1 = B[j0 + 1];
+    float pi0 = B[C::LD + i0], pi1 = B[C::LD + i0 + 1], pj0 = B[C::LD + j0], pj1 = B[C::LD + j0 + 1];
+    float qi0 = B[2 * C::LD + i0], qi1 = B[2 * C::LD + i0 + 1], qj0 = B[2 * C::LD + j0], qj1 = B[2 * C::LD + j0 + 1];
+    float ti0 = B[3 * C::LD + i0], ti1 = B[3 * C::LD + i0 + 1], tj0 = B[3 * C::LD + j0], tj1 = B[3 * C::LD + j0 + 1];
+    // (W b_j) for the two columns of the block
+    float u0n = wnn * nj0 + wn1 * pj0 + wn2 * qj0 + wn3 * tj0, u1n = wnn * nj1 + wn1 * pj1 + wn2 * qj1 + wn3 * tj1;
+    float u0p = wn1 * nj0 + w11 * pj0, u1p = wn1 * nj1 + w11 * pj1;
+    float u0q = wn2 * nj0 + w22 * qj0, u1q = wn2 * nj1 + w22 * qj1;
+    float u0t = wn3 * nj0 + w33 * tj0, u1t = wn3 * nj1 + w33 * tj1;
+    h00 += ni0 * u0n + pi0 * u0p + qi0 * u0q + ti0 * u0t;
+    h01 += ni0 * u1n + pi0 * u1p + qi0 * u1q + ti0 * u1t;
+    h10 += ni1 * u0n + pi1 * u0p + qi1 * u0q + ti1 * u0t;
+    h11 += ni1 * u1n + pi1 * u1p + qi1 * u1q + ti1 * u1t;
   }
   if (blk) {
     s.T[i0 * C::LD + j0] = h00; s.T[(i0 + 1) * C::LD + j0] = h10; s.T[(i0 + 1) * C::LD + j0 + 1] = h11;
@@ -189,7 +255,7 @@ struct SolveStats { int niter, ls_total; };
 // Newton solve.  In: Mrow (row i of M in lane i), fs = qfrc_smooth_i, a0 = qacc_smooth_i, warm_i.
 // Out: qacc_i, qfrc_constraint_i.
 template <class C>
-__device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const RowRegs (&rr)[C::NCHUNK],
+__device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
                       const float (&Mrow)[C::NV], float fs, float a0, float warm, float& qacc_out, float& qfc_out,
                       SolveStats& st PROF_ARG) {
   const bool dofl = lane < C::NV;
@@ -197,13 +263,13 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
   float a[C::NV], lt[C::NV];
   // --- warm start: the cheaper of qacc_warmstart and qacc_smooth (cost only) ---
   float Ma_w = dofl ? row_dot<C>(Mrow, warm) : 0.0f;
-  jdot<C>(s, lane, nefc, warm, tmp);
+  jdot<C>(s, lane, nefc, nbase, rr, warm, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
   float cost_w = rows_cost<C>(lane, nefc, jaref, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_w - fs) * (warm - a0) : 0.0f);
   float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
   float jar_s[C::NCHUNK];
-  jdot<C>(s, lane, nefc, a0, tmp);
+  jdot<C>(s, lane, nefc, nbase, rr, a0, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
   float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_s - fs) * (a0 - a0) : 0.0f);
@@ -218,10 +284,10 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
   float rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
   gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
   cost = rc + gauss;
-  float qfc = jt_force<C>(s, lane, nefc, force);
+  float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
   PROF(PS_SOLVE_INIT)
-  hessian_factor<C>(s, lane, nefc, hw, a, lt);
+  hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt);
   float search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
   PROF(PS_HESS)
   const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
@@ -239,7 +305,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     float snorm = sqrtf(wave_sum(search * search));
     float gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * (float)(C::NV > 1 ? C::NV : 1);
     float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
-    jdot<C>(s, lane, nefc, search, jv);
+    jdot<C>(s, lane, nefc, nbase, rr, search, jv);
     float g1 = wave_sum(search * Ma) - wave_sum(search * fs);
     float g2 = 0.5f * wave_sum(search * mv);
     // fp32 noise floor of the 1-D derivative: d0(alpha) = 2 alpha q2 + q1 is a sum of up to NEFC terms, so values
@@ -295,10 +361,10 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, const Row
     rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
     gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
     prev_cost = cost; cost = rc + gauss;
-    qfc = jt_force<C>(s, lane, nefc, force);
+    qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
     PROF(PS_UPD)
-    hessian_factor<C>(s, lane, nefc, hw, a, lt);
+    hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt);
     search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
     PROF(PS_HESS)
     ++iter;
@@ -336,10 +402,15 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
   collision<C>(m, s, lane);
   PROF(PS_COLL)
   RowRegs rr[C::NCHUNK];
-  int nefc = make_constraint<C>(m, s, lane, rr);
+  float bcoef[C::NCHUNK], jqv[C::NCHUNK];
+  int nbase;
+  int nefc = make_constraint<C>(m, s, lane, rr, bcoef, nbase);
+  jdot<C>(s, lane, nefc, nbase, rr, qvel_i, jqv);                 // aref = -b (J.qvel) - k imp pos
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) rr[ch].aref -= bcoef[ch] * jqv[ch];
   PROF(PS_ROWS)
   out.fsmooth = fs; out.nefc = nefc;
-  solve<C>(m, s, lane, nefc, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st PROF_PASS);
+  solve<C>(m, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
     if (lane == 0) {
@@ -361,7 +432,19 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
       int r = lane + 64 * ch;
       if (r < nefc && r < 256) { dbg[1152 + r] = rr[ch].aref; dbg[1408 + r] = rr[ch].D; }
     }
-    for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) dbg[2048 + t] = s.x.b.J[(t / C::NV) * C::LD + (t % C::NV)];
+    {
+      const int rcon = nefc - 6 * s.ncon;
+      for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) {
+        int r = t / C::NV, i = t % C::NV;
+        float v;
+        if (r < rcon) v = s.x.b.J[r * C::LD + i];
+        else {
+          int c = (r - rcon) / 6, e = (r - rcon) % 6, bn = rcon + 4 * c, bk = bn + 1 + (e >> 1);
+          v = s.x.b.J[bn * C::LD + i] + ((e & 1) ? -s.bmu[bk] : s.bmu[bk]) * s.x.b.J[bk * C::LD + i];
+        }
+        dbg[2048 + t] = v;
+      }
+    }
     for (int t = lane; t < C::NV * 6; t += 64) dbg[6528 + t] = s.cdof[t];
     for (int t = lane; t < C::NB * 3; t += 64) dbg[6800 + t] = s.com[t];
   }
