@@ -92,7 +92,8 @@ __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane
 template <class C>
 __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
-  __shared__ Smem<C> s;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   float* rec = a.state + (size_t)e * L.rec;
@@ -167,10 +168,17 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
 }
 
 // ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
+// LDS is dynamic so that the register budget is set by RSR_WAVES_PER_EU below, not by the compiler's
+// LDS-derived occupancy guess (which lands one register over the 2-waves/SIMD budget and halves residency).
+#ifndef RSR_WAVES_PER_EU
+#define RSR_WAVES_PER_EU 2
+#endif
 template <class C>
-__global__ __launch_bounds__(64) void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
+void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
-  __shared__ Smem<C> s;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= a.n) return;
   float* rec = a.state + (size_t)e * L.rec;
@@ -492,7 +500,7 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.keys = keys;
-  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dmodel,
+  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), static_cast<hipStream_t>(hip_stream), b->dmodel,
                      b->model->layout, a);
   HIPCHK(hipGetLastError());
   return RSR_OK;
@@ -503,7 +511,7 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.action = action;
-  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b->dmodel,
+  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), static_cast<hipStream_t>(hip_stream), b->dmodel,
                      b->model->layout, a);
   HIPCHK(hipGetLastError());
   if (b->timing) b->launches++;

@@ -99,14 +99,11 @@ __device__ __forceinline__ void ls_eval(int lane, int nefc, const float (&alpha)
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) q[p][c] = row_sum16(q[p][c]);
+    for (int c = 0; c < 3; ++c) q[p][c] = wave_sum(q[p][c]);     // independent DPP chains, interleaved by the scheduler
   }
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
-    float t[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) t[c] = (rdlane(q[p][c], 0) + rdlane(q[p][c], 16)) + (rdlane(q[p][c], 32) + rdlane(q[p][c], 48));
-    float q0 = t[0] + g0, q1 = t[1] + g1, q2 = t[2] + g2, al = alpha[p];
+    float q0 = q[p][0] + g0, q1 = q[p][1] + g1, q2 = q[p][2] + g2, al = alpha[p];
     out[p].alpha = al;
     out[p].cost = al * al * q2 + al * q1 + q0;
     out[p].d0 = 2.0f * al * q2 + q1;
@@ -322,7 +319,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase
     n2 = wave_sum(n2) + fabsf(g2);
     const float NOISE = 1.1920929e-7f;
     LSPoint p0 = ls_point<C>(lane, nefc, 0.0f, jaref, jv, rr, gauss, g1, g2);
-    LSPoint lo = ls_point<C>(lane, nefc, p0.alpha - p0.d0 / p0.d1, jaref, jv, rr, gauss, g1, g2), hi;
+    LSPoint lo = ls_point<C>(lane, nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), jaref, jv, rr, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     bool swap = true; int it = 0;
     while (true) {
@@ -333,7 +330,7 @@ __device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase
       ldone |= (lo.d0 < 0.0f) && (lo.d0 > -tol_lo);
       ldone |= (hi.d0 > 0.0f) && (hi.d0 < tol_hi);
       if (uniform_i(ldone)) break;
-      float al3[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, 0.5f * (lo.alpha + hi.alpha)};
+      float al3[3] = {lo.alpha - lo.d0 * __builtin_amdgcn_rcpf(lo.d1), hi.alpha - hi.d0 * __builtin_amdgcn_rcpf(hi.d1), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
       ls_eval<C, 3>(lane, nefc, al3, jaref, jv, rr, gauss, g1, g2, p3);
       LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
