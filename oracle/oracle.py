@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BATCH_FIELDS = [
     "qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos",
     "obs", "reward", "done", "metrics",
-    "info_target_pos", "info_new_cube_pos", "info_site_pos", "info_cube_pos",
+    "info_target_pos", "info_new_cube_pos", "info_site_pos", "info_cube_pos", "info_last_action",
     "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics",
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
     "first_obs",
@@ -90,7 +90,7 @@ class Oracle:
             qpos=z(self.nq), qvel=z(self.nv), ctrl=z(self.nu), qacc_warmstart=z(self.nv), time=z(),
             xpos=z(self.nbody, 3), site_xpos=z(self.nsite, 3),
             obs=z(self.obs_dim), reward=z(), done=z(), metrics=z(self.nmetrics),
-            info_target_pos=z(3), info_new_cube_pos=z(2), info_site_pos=z(3), info_cube_pos=z(3),
+            info_target_pos=z(3), info_new_cube_pos=z(2), info_site_pos=z(3), info_cube_pos=z(3), info_last_action=z(),
             info_steps=z(), info_truncation=z(), info_episode_done=z(), info_episode_metrics=z(2 + self.nmetrics),
             first_qpos=z(self.nq), first_qvel=z(self.nv), first_ctrl=z(self.nu), first_warmstart=z(self.nv),
             first_time=z(), first_xpos=z(self.nbody, 3), first_site_xpos=z(self.nsite, 3), first_obs=z(self.obs_dim),

@@ -1287,7 +1287,7 @@ typedef struct {
   int n;
   float *qpos, *qvel, *ctrl, *qacc_warmstart, *time, *xpos, *site_xpos;          /* pipeline_state */
   float *obs, *reward, *done, *metrics;                                          /* outputs */
-  float *info_target_pos, *info_new_cube_pos, *info_site_pos, *info_cube_pos;    /* env info */
+  float *info_target_pos, *info_new_cube_pos, *info_site_pos, *info_cube_pos, *info_last_action;    /* env info */
   float *info_steps, *info_truncation, *info_episode_done, *info_episode_metrics; /* wrapper info */
   float *first_qpos, *first_qvel, *first_ctrl, *first_warmstart, *first_time, *first_xpos, *first_site_xpos, *first_obs;
   float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;  /* NULL = model values */
@@ -1370,6 +1370,7 @@ static void reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], 
     s->info_cube_pos[3 * e + i] = xpos[3 * cube + i];
   }
   s->info_new_cube_pos[2 * e] = R[25]; s->info_new_cube_pos[2 * e + 1] = R[26];
+  s->info_last_action[e] = 0;
   s->reward[e] = 0; s->done[e] = 0;
   for (int i = 0; i < m->nmetrics; i++) s->metrics[e * m->nmetrics + i] = 0;
   cube_obs(m, &s->qpos[e * m->nq], &sx[3 * site], &s->info_target_pos[3 * e], &xpos[3 * cube],
@@ -1413,6 +1414,12 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
     float ang = atan2f(dy, dxe);
     volatile float t1 = -ang + act[0];
     act[4] = t1 + 1.5708f;
+    if (m->env_kind == ENV_AIRBOT_SF) {   /* test/airbot.py:180-184: hold the wrist target once the cube is within 3 cm */
+      float dz = tp[2] - xpos[3 * cube + 2];
+      float btd0 = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (btd0 < 0.03f) act[4] = s->info_last_action[e];
+      s->info_last_action[e] = act[4];
+    }
   }
   for (int i = 0; i < nu; i++) act[i] = act[i] < m->env_ctrl_lo[i] ? m->env_ctrl_lo[i] : (act[i] > m->env_ctrl_hi[i] ? m->env_ctrl_hi[i] : act[i]);
   /* --- pipeline_step: n_frames x mjx.step with the same ctrl --- */
@@ -1425,10 +1432,12 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
   float cp[3] = {xpos[3 * cube], xpos[3 * cube + 1], xpos[3 * cube + 2]};
   float sp[3] = {sx[3 * site], sx[3 * site + 1], sx[3 * site + 2]};
   float d0 = tp[0] - cp[0], d1 = tp[1] - cp[1], d2 = tp[2] - cp[2];
+  const int sf = m->env_kind == ENV_AIRBOT_SF;
   float box_target_dis = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-  if (box_target_dis < 0.005f) box_target_dis = 0.0f;
+  if (box_target_dis < W[4]) box_target_dis = 0.0f;          /* 0.005 (cube_env.py:166) / 0.003 (test/airbot.py:191) */
   float push_reward = 1.0f / (1.0f + 3.0f * box_target_dis);
   push_reward = push_reward * W[0];
+  float task_complete = box_target_dis < W[4] ? W[5] : 0.0f;  /* test/airbot.py:196 */
   float old_ncp[2] = {ncp[0], ncp[1]};
   float site_z_reward = sp[2] < 0.82f ? 1.0f : 0.0f;
   float delta_x = tp[0] - cp[0], delta_y = tp[1] - cp[1];
@@ -1442,9 +1451,11 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
   s2c = s2c < 0.042f ? 0.0f : s2c - 0.042f;
   float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
   if (box_target_dis < 0.005f) siet = W[1];
-  float health = W[2] * fabsf((sp[2] < W[3] ? 1.0f : 0.0f) - 1.0f);
-  float reward = push_reward + siet + health + site_z_reward;
-  float done = cp[2] < 0.6f ? 1.0f : 0.0f;
+  float hd = sp[2] < W[3] ? 1.0f : 0.0f;
+  if (sf && (sp[0] > 1.0f || sp[0] < -0.6f || sp[1] > 0.3f || sp[1] < -0.3f || cp[2] < 0.6f)) hd = 1.0f;   /* test/airbot.py:227-233 */
+  float health = W[2] * fabsf(hd - 1.0f);
+  float reward = sf ? push_reward + siet + health + task_complete + site_z_reward : push_reward + siet + health + site_z_reward;
+  float done = sf ? (box_target_dis < W[4] ? 1.0f : 0.0f) : (cp[2] < 0.6f ? 1.0f : 0.0f);
   reward = reward < -100.0f ? -100.0f : (reward > 100.0f ? 100.0f : reward);
   cube_obs(m, qpos, sp, tp, cp, ncp, &s->obs[e * m->obs_dim]);
   s->metrics[e * m->nmetrics + 0] = push_reward;
@@ -1481,7 +1492,7 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
 
 /* ------------------------------------------------------------------ exported batch entry points */
 int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threads) {
-  if (m->env_kind != ENV_CUBE) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -1498,7 +1509,7 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
 }
 
 int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads) {
-  if (m->env_kind != ENV_CUBE) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel

@@ -59,7 +59,7 @@ struct DModel {
 struct Layout {
   int qpos, qvel, ctrl, warm, time, xpos, site_xpos;
   int obs, reward, done, metrics;
-  int target_pos, new_cube_pos, site_pos, cube_pos, steps, truncation, episode_done, episode_metrics;
+  int target_pos, new_cube_pos, site_pos, cube_pos, last_action, steps, truncation, episode_done, episode_metrics;
   int f_qpos, f_qvel, f_ctrl, f_warm, f_time, f_xpos, f_site_xpos, f_obs;
   int stats;
   int rec;            // floats per env (multiple of 16)
@@ -228,7 +228,7 @@ struct Smem {
 // register-only steps instead of nbody LDS round trips.  Bodies carry at most one joint (checked on the host).
 // =====================================================================================
 template <class C>
-__device__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
   static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64, "one lane per body / geom / joint");
   const int b = lane < C::NB ? lane : 0;
   const int parent = m.body_parentid[b], depth = lane < C::NB ? m.body_depth[b] : -1;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void inert_mul(float* o, const float* i, const float*
 // stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
 // =====================================================================================
 template <class C>
-__device__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
   // subtree centre of mass: lane b sums its subtree
   if (lane < C::NB) {
     unsigned mask = m.body_submask[lane];
@@ -686,7 +686,7 @@ __device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
 }
 
 template <class C>
-__device__ void collision(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane) {
   CPts pts; pts.cnt = 0;
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
@@ -744,7 +744,7 @@ __device__ __forceinline__ void motion_cross(float* o, const float* u, const flo
 }
 
 template <class C>
-__device__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
+__device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
   // cvel[b] = sum over the dofs on b's chain of cdof*qvel
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
@@ -866,7 +866,7 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
 // Returns nefc; rr[] holds the per-row scalars except the velocity part of aref: the caller finishes
 // aref -= bcoef * (J.qvel) once the base rows are in LDS (it owns the J.v machinery).
 template <class C>
-__device__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
+__device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
                                int& nbase_out) {
   constexpr int LD = C::LD;
   // active joint limits, compacted in joint order

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
       rec[L.cube_pos + i] = s.xpos[3 * cube + i];
     }
     rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+    rec[L.last_action] = 0.0f;
     cube_obs<C>(m, s, tp, ncp, obs);
     for (int i = 0; i < C::OBS; ++i) { rec[L.obs + i] = obs[i]; rec[L.f_obs + i] = obs[i]; }
     rec[L.reward] = 0.0f; rec[L.done] = 0.0f;
@@ -208,6 +209,11 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
       float dx = tp[0] - rec[L.xpos + 3 * cube], dy = tp[1] - rec[L.xpos + 3 * cube + 1];
       float ang = atan2f(dy, dx + 0.00001f);
       act = (-ang + act0) + 1.5708f;
+      if (m.env_kind == ENV_AIRBOT_SF) {      // test/airbot.py:180-184: hold the wrist target within 3 cm of the goal
+        float dz = tp[2] - rec[L.xpos + 3 * cube + 2];
+        if (sqrtf(dx * dx + dy * dy + dz * dz) < 0.03f) act = rec[L.last_action];
+        rec[L.last_action] = act;
+      }
     }
     s.ctrl[lane] = clampf(act, m.env_ctrl_lo[lane], m.env_ctrl_hi[lane]);
   }
@@ -235,9 +241,11 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float cp[3] = {s.xpos[3 * cube], s.xpos[3 * cube + 1], s.xpos[3 * cube + 2]};
     float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
     float d0 = tp[0] - cp[0], d1 = tp[1] - cp[1], d2 = tp[2] - cp[2];
+    const bool sf = m.env_kind == ENV_AIRBOT_SF;
     float btd = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    if (btd < 0.005f) btd = 0.0f;
+    if (btd < W[4]) btd = 0.0f;                       // 0.005 (cube_env.py:166) / 0.003 (test/airbot.py:191)
     float push = (1.0f / (1.0f + 3.0f * btd)) * W[0];
+    float task_complete = btd < W[4] ? W[5] : 0.0f;   // test/airbot.py:196
     float site_z = sp[2] < 0.82f ? 1.0f : 0.0f;
     float dx = tp[0] - cp[0], dy = tp[1] - cp[1];
     float ang = atan2f(dy, dx + 0.00001f);
@@ -249,9 +257,11 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     s2c = s2c < 0.042f ? 0.0f : s2c - 0.042f;
     float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
     if (btd < 0.005f) siet = W[1];
-    float health = W[2] * fabsf((sp[2] < W[3] ? 1.0f : 0.0f) - 1.0f);
-    float reward = clampf(push + siet + health + site_z, -100.0f, 100.0f);
-    done = cp[2] < 0.6f ? 1.0f : 0.0f;
+    float hd = sp[2] < W[3] ? 1.0f : 0.0f;
+    if (sf && (sp[0] > 1.0f || sp[0] < -0.6f || sp[1] > 0.3f || sp[1] < -0.3f || cp[2] < 0.6f)) hd = 1.0f;   // test/airbot.py:227-233
+    float health = W[2] * fabsf(hd - 1.0f);
+    float reward = clampf(sf ? push + siet + health + task_complete + site_z : push + siet + health + site_z, -100.0f, 100.0f);
+    done = sf ? (btd < W[4] ? 1.0f : 0.0f) : (cp[2] < 0.6f ? 1.0f : 0.0f);
     cube_obs<C>(m, s, tp, ncp, obs_lds);
     rec[L.metrics + 0] = push; rec[L.metrics + 2] = siet;
     for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.cube_pos + i] = cp[i]; }
@@ -350,7 +360,7 @@ static Layout make_layout(const rsr_dims& d) {
   L.f_xpos = take(d.nbody * 3); L.f_site_xpos = take(d.nsite * 3);
   L.obs = take(d.obs_dim); L.f_obs = take(d.obs_dim);
   L.reward = take(1); L.done = take(1); L.metrics = take(d.nmetrics);
-  L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3);
+  L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3); L.last_action = take(1);
   L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
   L.stats = take(4);
   L.rec = (o + 15) & ~15;
@@ -374,10 +384,10 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   d.env_kind = ei[0]; d.n_frames = ei[1]; d.episode_length = ei[2]; d.obs_dim = ei[4]; d.nmetrics = ei[5];
   using C = rsr::CubeDims;
   const int* c2 = static_cast<const int*>(m->find("counts2"));
-  bool ok = d.env_kind == rsr::ENV_CUBE && d.nq == C::NQ && d.nv == C::NV && d.nu == C::NU && d.nbody == C::NB &&
+  bool ok = (d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) && d.nq == C::NQ && d.nv == C::NV && d.nu == C::NU && d.nbody == C::NB &&
             d.njnt == C::NJ && d.ngeom == C::NG && d.nsite == C::NS && d.npair == C::NP && d.neq == C::NEQ && c2 &&
             c2[0] == C::NF && c2[1] == C::NL && d.obs_dim == C::OBS && d.nmetrics == C::NMET;
-  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube)"); }
+  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf)"); }
   if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
   for (int i = 0; i < npc; ++i) if (pc[i] != 4) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: only condim-4 contact pairs are built"); }
@@ -539,6 +549,7 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_INFO_NEW_CUBE_POS: off = L.new_cube_pos; w = 2; break;
     case RSR_F_INFO_SITE_POS: off = L.site_pos; w = 3; break;
     case RSR_F_INFO_CUBE_POS: off = L.cube_pos; w = 3; break;
+    case RSR_F_INFO_LAST_ACTION: off = L.last_action; w = 1; break;
     case RSR_F_INFO_STEPS: off = L.steps; w = 1; break;
     case RSR_F_INFO_TRUNCATION: off = L.truncation; w = 1; break;
     case RSR_F_INFO_EPISODE_DONE: off = L.episode_done; w = 1; break;

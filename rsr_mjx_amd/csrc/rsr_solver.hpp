@@ -252,7 +252,7 @@ struct SolveStats { int niter, ls_total; };
 // Newton solve.  In: Mrow (row i of M in lane i), fs = qfrc_smooth_i, a0 = qacc_smooth_i, warm_i.
 // Out: qacc_i, qfrc_constraint_i.
 template <class C>
-__device__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
+__device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
                       const float (&Mrow)[C::NV], float fs, float a0, float warm, float& qacc_out, float& qfc_out,
                       SolveStats& st PROF_ARG) {
   const bool dofl = lane < C::NV;
@@ -377,7 +377,7 @@ struct FwdOut { float qacc, qfc, fsmooth; int nefc; SolveStats st; };
 // MJX forward(): position -> collision -> constraint rows -> velocity/actuation -> solve.
 // warm_i is read and replaced by the solver's qacc (qacc_warmstart <- qacc).
 template <class C>
-__device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
+__device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
                         float* dbg PROF_ARG) {
   kinematics<C>(m, s, lane);
   PROF(PS_KIN)
@@ -449,7 +449,7 @@ __device__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::
 
 // integrate one substep after forward(): implicitfast / Euler, then _advance
 template <class C>
-__device__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
+__device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
   float qacc = f.qacc;
   bool implicit = m.integrator == INT_IMPLICITFAST;
   if (m.integrator == INT_EULER && !m.disable_eulerdamp) {

@@ -66,18 +66,22 @@ class State:
 class AirbotPlayBase:
     """Env definition (model + task constants).  `reset`/`step` run a batch sized by the keys."""
 
+    _default_asset = "airbot_cube.npz"
+    _fields_fn = staticmethod(cfg.cube_env_fields)
+    _defaults = cfg.CUBE_DEFAULTS
+
     def __init__(self, model_path: Optional[str] = None, device: str = "cuda:0", **kwargs):
         if model_path is None:
-            self.sys: CompiledModel = CompiledModel.load(os.path.join(_ASSETS, "airbot_cube.npz"))
+            self.sys: CompiledModel = CompiledModel.load(os.path.join(_ASSETS, self._default_asset))
         elif model_path.endswith(".npz"):
             self.sys = CompiledModel.load(model_path)
         else:
             self.sys = compile_mjcf(model_path)     # reference: mujoco.MjModel.from_xml_path("cube.xml")
         self._kwargs = dict(kwargs)
         self._device = device
-        self._n_frames = kwargs.get("n_frames", kwargs.get("decimation", cfg.CUBE_DEFAULTS["decimation"]))
+        self._n_frames = kwargs.get("n_frames", kwargs.get("decimation", self._defaults["decimation"]))
         self._batched: Optional[BatchedEnv] = None
-        cfg.cube_env_fields(self.sys, **self._kwargs)   # validates kwargs early, like the reference constructor
+        self._fields_fn(self.sys, **self._kwargs)       # validates kwargs early, like the reference constructor
 
     # --- reference properties ---
     @property
@@ -115,6 +119,15 @@ class AirbotPlayBase:
         return self._batched.step(state, action)
 
 
+class AirbotPlaySF(AirbotPlayBase):
+    """The variant every RSR script uses (reference test/airbot.py, model test/sf.xml): wrist target held within 3 cm
+    of the goal, task-complete bonus, done = cube at target."""
+
+    _default_asset = "airbot_sf.npz"
+    _fields_fn = staticmethod(cfg.sf_env_fields)
+    _defaults = cfg.SF_DEFAULTS
+
+
 class BatchedEnv:
     """N envs on one GPU behind the C ABI; optionally with the Episode/AutoReset wrapper semantics fused."""
 
@@ -129,7 +142,7 @@ class BatchedEnv:
             raise RuntimeError("the stepper runs on a HIP device only (torch device 'cuda:N')")
         L = _lib.lib()
         f = model_fields(self.sys)
-        f.update(cfg.cube_env_fields(self.sys, episode_length=self.episode_length, auto_reset=self.auto_reset, **env._kwargs))
+        f.update(env._fields_fn(self.sys, episode_length=self.episode_length, auto_reset=self.auto_reset, **env._kwargs))
         self.blob = pack_blob(f)
         buf = C.create_string_buffer(self.blob, len(self.blob))
         self._model = C.c_void_p()
@@ -227,6 +240,8 @@ class BatchedEnv:
             "site_pos": v["info_site_pos"], "cube_pos": v["info_cube_pos"],
             "reached_box": self.record.new_zeros((n,)),
         }
+        if isinstance(self.env, AirbotPlaySF):
+            info["last_action"] = v["info_last_action"][:, 0]
         if self.episode_length > 0:
             em = v["info_episode_metrics"]
             info.update(steps=v["info_steps"][:, 0], truncation=v["info_truncation"][:, 0],

@@ -27,8 +27,20 @@ CUBE_OBS_DIM = 23
 CUBE_METRICS = ("push_reward", "ctrl_cost", "siet_to_box_reward")
 
 
-def cube_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool = False, **kwargs) -> Dict[str, np.ndarray]:
-    cfg = dict(CUBE_DEFAULTS)
+# test/airbot.py:10-42: the variant every RSR script uses (model test/sf.xml)
+SF_DEFAULTS = dict(CUBE_DEFAULTS, endpoint_min_z_pos=0.8, reset_action_scale=0.03,
+                   cube_min_x=0.28, cube_max_x=0.29, cube_min_y=-0.005, cube_max_y=0.005,
+                   target_min_x=0.5, target_max_x=0.51, target_min_y=-0.005, target_max_y=0.005)
+
+
+def sf_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool = False, **kwargs) -> Dict[str, np.ndarray]:
+    return cube_env_fields(m, episode_length, auto_reset, _kind=ENV_AIRBOT_SF, **kwargs)
+
+
+def cube_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool = False, _kind: int = ENV_CUBE,
+                    **kwargs) -> Dict[str, np.ndarray]:
+    kind = _kind
+    cfg = dict(SF_DEFAULTS if kind == ENV_AIRBOT_SF else CUBE_DEFAULTS)
     n_frames = kwargs.pop("n_frames", None)
     unknown = set(kwargs) - set(cfg)
     if unknown:
@@ -53,10 +65,12 @@ def cube_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool 
          cfg["cube_min_x"], cfg["cube_min_y"], 0.82, cfg["cube_max_x"], cfg["cube_max_y"], 0.82,
          0.37342, -0.07989],                                              # :127
         dtype=np.float32)
+    # [push weight, siet weight, healthy reward, endpoint_min_z, "at target" threshold, task-complete bonus]
     reward = np.array([cfg["push_reward_weight"], cfg["siet_to_box_reward_weight"], cfg["healthy_reward"],
-                       cfg["endpoint_min_z_pos"]], dtype=np.float32)
+                       cfg["endpoint_min_z_pos"], 0.003 if kind == ENV_AIRBOT_SF else 0.005,
+                       5.0 if kind == ENV_AIRBOT_SF else 0.0], dtype=np.float32)
     return dict(
-        env_int=np.array([ENV_CUBE, n_frames, episode_length, flags, CUBE_OBS_DIM, len(CUBE_METRICS)], dtype=np.int32),
+        env_int=np.array([kind, n_frames, episode_length, flags, CUBE_OBS_DIM, len(CUBE_METRICS)], dtype=np.int32),
         env_ids=ids,
         env_action_scale=np.array([0.02, 0.02, 0.02, 0.0, 0.0], dtype=np.float32),   # cube_env.py:60
         env_ctrl_lo=A["actuator_ctrlrange"][:, 0].astype(np.float32),                 # :63-64

@@ -204,3 +204,49 @@ def test_domain_randomisation_inputs(cube_model, oracle_mod):
     for _ in range(5):
         orc.step(a, act); orc.step(b, act)
     assert np.abs(a["qvel"] - b["qvel"]).max() > 1e-6
+
+
+def test_sf_variant_follows_test_airbot_py(sf_model, oracle_mod):
+    """reference test/airbot.py: wrist target held within 3 cm (:180-184), thresholds 0.003, task-complete bonus 5 (:196),
+    health from the done chain (:227-233), done = cube at target (:236-237)."""
+    f = np.float32
+    orc = oracle_mod.Oracle(make_blob(sf_model, kind="sf"))
+    n = 32
+    st = orc.new_state(n)
+    keys = prng.split(prng.PRNGKey(12), n)
+    orc.reset(st, keys)
+    # reset ranges of the variant (test/airbot.py:32-39)
+    assert np.all((st["qpos"][:, 15] >= 0.28) & (st["qpos"][:, 15] <= 0.29)) and np.all((st["qpos"][:, 8] >= 0.5) & (st["qpos"][:, 8] <= 0.51))
+    assert np.all(st["info_last_action"] == 0)
+    rng = np.random.default_rng(12)
+    for t in range(25):
+        pre = _snap(st)
+        if t == 10:        # teleport half of the cubes next to their targets to exercise the hold / bonus / done branches
+            st["qpos"][: n // 2, 15:18] = st["info_target_pos"][: n // 2] + f(0.001)
+            st["xpos"][: n // 2, 13] = st["qpos"][: n // 2, 15:18]
+            pre = _snap(st)
+        a = rng.uniform(-1, 1, (n, 5)).astype(f)
+        orc.step(st, a)
+        tp, cp0 = pre["info_target_pos"], pre["xpos"][:, 13]
+        act0 = pre["ctrl"][:, 0] + f(0.02) * a[:, 0]
+        dx, dy = tp[:, 0] - cp0[:, 0], tp[:, 1] - cp0[:, 1]
+        free = (-np.arctan2(dy, dx + f(0.00001)).astype(f) + act0) + f(1.5708)
+        btd0 = np.sqrt(((tp - cp0) ** 2).sum(-1, dtype=f)).astype(f)
+        want_last = np.where(btd0 < f(0.03), pre["info_last_action"], free)
+        np.testing.assert_allclose(st["info_last_action"], want_last, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(st["ctrl"][:, 4], np.clip(want_last, -3.14, 3.14), rtol=1e-6, atol=1e-6)
+        cp, sp = st["xpos"][:, 13], st["site_xpos"][:, 0]
+        btd = np.sqrt(((tp - cp) ** 2).sum(-1, dtype=f)).astype(f)
+        btd = np.where(btd < f(0.003), f(0), btd)
+        push = (f(1) / (f(1) + f(3) * btd)) * f(6)
+        bonus = np.where(btd < f(0.003), f(5), f(0))
+        s2c = np.sqrt(((sp[:, :2] - pre["info_new_cube_pos"]) ** 2).sum(-1, dtype=f)).astype(f)
+        s2c = np.where(s2c < f(0.042), f(0), s2c - f(0.042))
+        siet = np.where(btd < f(0.005), f(3), (f(1) - np.tanh(f(5) * s2c).astype(f)) * f(3))
+        hd = (sp[:, 2] < f(0.8)) | (sp[:, 0] > 1.0) | (sp[:, 0] < -0.6) | (sp[:, 1] > 0.3) | (sp[:, 1] < -0.3) | (cp[:, 2] < 0.6)
+        health = f(1) * np.abs(hd.astype(f) - f(1))
+        reward = np.clip(push + siet + health + bonus + np.where(sp[:, 2] < f(0.82), f(1), f(0)), -100, 100)
+        np.testing.assert_allclose(st["reward"], reward, rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(st["done"], (btd < f(0.003)).astype(f))
+        if t == 10:
+            assert st["done"][: n // 2].min() == 1.0 and np.all(st["reward"][: n // 2] >= 6 + 3 + 5)

@@ -146,6 +146,37 @@ def test_truncation_and_autoreset_on_device(setup, oracle_mod):
             np.testing.assert_array_equal(_np(env, "qpos", st["qpos"]), _np(env, "first_qpos", st["qpos"]))
 
 
+def test_sf_variant_parity(setup, oracle_mod):
+    """reference test/airbot.py (model test/sf.xml): same kernel, different prologue/epilogue constants and info."""
+    import torch
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.envs.airbot import AirbotPlaySF
+    n = 256
+    env = AirbotPlaySF(device="cuda:0").batched(n, episode_length=1200, auto_reset=True)
+    orc = oracle_mod.Oracle(env.blob)
+    orc.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(21), n)
+    st = orc.new_state(n)
+    orc.reset(st, keys)
+    state = env.reset(keys)
+    rng = np.random.default_rng(21)
+    fields = SHARED + ["info_last_action"]
+    for t in range(12):
+        if t == 6:      # put half of the cubes on their targets: hold / bonus / done branches
+            st["qpos"][: n // 2, 15:18] = st["info_target_pos"][: n // 2] + np.float32(0.001)
+            st["xpos"][: n // 2, 13] = st["qpos"][: n // 2, 15:18]
+        for k in fields:
+            env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        act = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+        orc.step(st, act)
+        state = env.step(state, act)
+        torch.cuda.synchronize()
+        _check_strict(env, st, None, fields=["obs", "reward", "metrics", "info_last_action", "ctrl", "xpos"], tag=f"sf step {t}")
+        for k in EXACT:
+            np.testing.assert_array_equal(_np(env, k, st[k]), st[k], err_msg=f"{k} at step {t}")
+    assert "last_action" in state.info
+
+
 def test_golden_fixture_configs0(setup):
     """BASELINE.json configs[0] (N=4, 200 steps): teacher-forced steps from the committed oracle snapshots."""
     import torch
