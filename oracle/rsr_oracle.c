@@ -1289,6 +1289,8 @@ typedef struct {
   float *obs, *reward, *done, *metrics;                                          /* outputs */
   float *info_target_pos, *info_new_cube_pos, *info_site_pos, *info_cube_pos, *info_last_action;    /* env info */
   float *info_steps, *info_truncation, *info_episode_done, *info_episode_metrics; /* wrapper info */
+  /* T-shape env info (T_shape_env.py:127-134); NULL for the cube envs */
+  float *info_target_base_pos, *info_target_vertical_pos, *info_target_w, *info_new_T_pos, *info_T_pos, *info_xita;
   float *first_qpos, *first_qvel, *first_ctrl, *first_warmstart, *first_time, *first_xpos, *first_site_xpos, *first_obs;
   float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;  /* NULL = model values */
   int *stats;   /* [n][4]: solver iterations, line-search iterations, ncon, overflow (last substep) */
@@ -1490,9 +1492,188 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
   }
 }
 
+/* ================================================================== T-shape env (T_shape_env.py) */
+/* env_ids: 0 T body, 1 target body, 2 endpoint site, 3 T_tail site, 4 T_target_tail site, 5 base_block geom,
+ * 6 vertical_block geom, 7 base_target geom, 8 vertical_target geom, 9..14 arm joint qposadr
+ * env_reset: 0 noise, 1..6 arm offsets, 7..11 ctrl init, 12..13 new_T_pos0, 14 xita0
+ * env_reward: 0 push weight, 1 siet weight, 2 healthy reward, 3 endpoint_min_z */
+enum { TID_T = 0, TID_TARGET = 1, TID_SITE = 2, TID_TAIL = 3, TID_TTAIL = 4, TID_GBASE = 5, TID_GVERT = 6, TID_GTBASE = 7,
+       TID_GTVERT = 8, TID_JOINTQ = 9 };
+
+/* T_shape_env.py:223-234 */
+static void tshape_obs(const omodel *m, const float *qpos, const float *site, const float *gbase, const float *gvert,
+                       const float *tb, const float *tv, float xita, const float *newT, float *obs) {
+  for (int i = 0; i < 6; i++) obs[i] = qpos[m->env_ids[TID_JOINTQ + i]];
+  obs[6] = site[2];
+  for (int i = 0; i < 3; i++) { obs[7 + i] = tb[i] - gbase[i]; obs[10 + i] = tv[i] - gvert[i]; }
+  obs[13] = xita;
+  obs[14] = newT[0] - site[0]; obs[15] = newT[1] - site[1];
+}
+
+static void wrappers_reset(const omodel *m, obatch *s, int e) {
+  s->info_steps[e] = 0; s->info_truncation[e] = 0; s->info_episode_done[e] = 0;
+  for (int i = 0; i < 2 + m->nmetrics; i++) s->info_episode_metrics[e * (2 + m->nmetrics) + i] = 0;
+  memcpy(&s->first_qpos[e * m->nq], &s->qpos[e * m->nq], sizeof(float) * (size_t)m->nq);
+  memcpy(&s->first_qvel[e * m->nv], &s->qvel[e * m->nv], sizeof(float) * (size_t)m->nv);
+  memcpy(&s->first_ctrl[e * m->nu], &s->ctrl[e * m->nu], sizeof(float) * (size_t)m->nu);
+  memcpy(&s->first_warmstart[e * m->nv], &s->qacc_warmstart[e * m->nv], sizeof(float) * (size_t)m->nv);
+  s->first_time[e] = s->time[e];
+  memcpy(&s->first_xpos[e * m->nbody * 3], &s->xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
+  memcpy(&s->first_site_xpos[e * m->nsite * 3], &s->site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
+  memcpy(&s->first_obs[e * m->obs_dim], &s->obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+}
+
+/* Episode + AutoReset post-step (brax.envs.training.wrap), shared by all envs */
+static void wrappers_post(const omodel *m, obatch *s, int e, float reward) {
+  const int wrap_episode = m->wrap_flags & 1, wrap_autoreset = (m->wrap_flags & 2) != 0;
+  if (wrap_episode) {
+    float steps = s->info_steps[e] + 1.0f;
+    int over = steps >= (float)m->episode_length;
+    float done_env = s->done[e];
+    s->info_truncation[e] = over ? 1.0f - done_env : 0.0f;
+    s->info_steps[e] = steps;
+    float prev_done = s->info_episode_done[e];
+    float *em = &s->info_episode_metrics[e * (2 + m->nmetrics)];
+    em[0] = (em[0] + reward) * (1.0f - prev_done);
+    em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
+    for (int i = 0; i < m->nmetrics; i++) em[2 + i] = (em[2 + i] + s->metrics[e * m->nmetrics + i]) * (1.0f - prev_done);
+    if (over) s->done[e] = 1.0f;
+    s->info_episode_done[e] = s->done[e];
+  }
+  if (wrap_autoreset && s->done[e] != 0) {
+    memcpy(&s->qpos[e * m->nq], &s->first_qpos[e * m->nq], sizeof(float) * (size_t)m->nq);
+    memcpy(&s->qvel[e * m->nv], &s->first_qvel[e * m->nv], sizeof(float) * (size_t)m->nv);
+    memcpy(&s->ctrl[e * m->nu], &s->first_ctrl[e * m->nu], sizeof(float) * (size_t)m->nu);
+    memcpy(&s->qacc_warmstart[e * m->nv], &s->first_warmstart[e * m->nv], sizeof(float) * (size_t)m->nv);
+    s->time[e] = s->first_time[e];
+    memcpy(&s->xpos[e * m->nbody * 3], &s->first_xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
+    memcpy(&s->site_xpos[e * m->nsite * 3], &s->first_site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
+    memcpy(&s->obs[e * m->obs_dim], &s->first_obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+  }
+}
+
+/* T_shape_env.py:98-137 */
+static void tshape_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], odata *d) {
+  const float *R = m->env_reset;
+  uint32_t keys[5][2];
+  oracle_split(key, 5, &keys[0][0]);
+  float lo = -R[0], hi = R[0], u[NQ_MAX];
+  oracle_uniform(keys[1], m->nq, &lo, &hi, 0, u);
+  float qpos[NQ_MAX], qvel[NV_MAX], ctrl[NU_MAX];
+  for (int i = 0; i < m->nq; i++) qpos[i] = m->qpos0[i] + u[i];
+  for (int i = 0; i < 6; i++) qpos[m->env_ids[TID_JOINTQ + i]] += R[1 + i];
+  oracle_uniform(keys[2], m->nv, &lo, &hi, 0, qvel);
+  oracle_uniform(keys[3], m->nu, &lo, &hi, 0, u);
+  for (int i = 0; i < m->nu; i++) ctrl[i] = R[7 + i] + u[i];
+  s->time[e] = 0;
+  for (int i = 0; i < m->nq; i++) s->qpos[e * m->nq + i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) { s->qvel[e * m->nv + i] = qvel[i]; s->qacc_warmstart[e * m->nv + i] = 0; }
+  for (int i = 0; i < m->nu; i++) s->ctrl[e * m->nu + i] = 0;
+  load_env(m, s, e, d);
+  forward(m, d);
+  for (int i = 0; i < m->nu; i++) d->ctrl[i] = ctrl[i];
+  store_pipeline(m, s, e, d);
+  const int *id = m->env_ids;
+  float gb[3], gv[3];
+  for (int i = 0; i < 3; i++) {
+    s->info_target_base_pos[3 * e + i] = (float)d->geom_xpos[3 * id[TID_GTBASE] + i];
+    s->info_target_vertical_pos[3 * e + i] = (float)d->geom_xpos[3 * id[TID_GTVERT] + i];
+    s->info_site_pos[3 * e + i] = (float)d->site_xpos[3 * id[TID_SITE] + i];
+    s->info_T_pos[3 * e + i] = (float)d->xpos[3 * id[TID_T] + i];
+    gb[i] = (float)d->geom_xpos[3 * id[TID_GBASE] + i]; gv[i] = (float)d->geom_xpos[3 * id[TID_GVERT] + i];
+  }
+  s->info_target_w[e] = (float)d->xquat[4 * id[TID_TARGET]] * 10.0f;
+  s->info_new_T_pos[2 * e] = R[12]; s->info_new_T_pos[2 * e + 1] = R[13];
+  s->info_xita[e] = R[14];
+  s->reward[e] = 0; s->done[e] = 0;
+  for (int i = 0; i < m->nmetrics; i++) s->metrics[e * m->nmetrics + i] = 0;
+  tshape_obs(m, &s->qpos[e * m->nq], &s->site_xpos[e * m->nsite * 3 + 3 * id[TID_SITE]], gb, gv, &s->info_target_base_pos[3 * e],
+             &s->info_target_vertical_pos[3 * e], s->info_xita[e], &s->info_new_T_pos[2 * e], &s->obs[e * m->obs_dim]);
+  wrappers_reset(m, s, e);
+}
+
+/* T_shape_env.py:139-221 */
+static void tshape_step_env(const omodel *m, obatch *s, int e, const float *action, odata *d) {
+  const int nq = m->nq, nu = m->nu;
+  const int *id = m->env_ids;
+  float *qpos = &s->qpos[e * nq], *sx = &s->site_xpos[e * m->nsite * 3];
+  if ((m->wrap_flags & 2) != 0) { if (s->done[e] != 0) s->info_steps[e] = 0; s->done[e] = 0; }
+  float act[NU_MAX];
+  for (int i = 0; i < nu; i++) {
+    volatile float delta = m->env_action_scale[i] * action[e * nu + i];
+    act[i] = s->ctrl[e * nu + i] + delta;
+  }
+  {
+    volatile float t1 = 1.57f + qpos[id[TID_JOINTQ + 1]];
+    volatile float t2 = t1 + qpos[id[TID_JOINTQ + 2]];
+    act[3] = -t2;
+  }
+  {   /* wrist aims from the end effector at the T's tail site (both from the previous forward pass) */
+    float dx = sx[3 * id[TID_TAIL]] - sx[3 * id[TID_SITE]], dy = sx[3 * id[TID_TAIL] + 1] - sx[3 * id[TID_SITE] + 1];
+    volatile float dxe = dx + 0.00001f;
+    float ang = atan2f(dy, dxe);
+    volatile float t1 = -ang + act[0];
+    act[4] = t1 + 1.5708f;
+  }
+  for (int i = 0; i < nu; i++) act[i] = act[i] < m->env_ctrl_lo[i] ? m->env_ctrl_lo[i] : (act[i] > m->env_ctrl_hi[i] ? m->env_ctrl_hi[i] : act[i]);
+  load_env(m, s, e, d);
+  for (int i = 0; i < nu; i++) d->ctrl[i] = act[i];
+  for (int f = 0; f < m->n_frames; f++) step_physics(m, d);
+  store_pipeline(m, s, e, d);
+  const float *W = m->env_reward;
+  float gb[3], gv[3], sp[3], tail[3], ttail[3];
+  for (int i = 0; i < 3; i++) {
+    gb[i] = (float)d->geom_xpos[3 * id[TID_GBASE] + i]; gv[i] = (float)d->geom_xpos[3 * id[TID_GVERT] + i];
+    sp[i] = sx[3 * id[TID_SITE] + i]; tail[i] = sx[3 * id[TID_TAIL] + i]; ttail[i] = sx[3 * id[TID_TTAIL] + i];
+  }
+  const float *tb = &s->info_target_base_pos[3 * e], *tv = &s->info_target_vertical_pos[3 * e];
+  float a0 = tb[0] - gb[0], a1 = tb[1] - gb[1], a2 = tb[2] - gb[2];
+  float dis_base = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  if (dis_base < 0.005f) dis_base = 0.0f;
+  float push_base = 1.0f / (1.0f + 10.0f * dis_base);
+  float b0 = tv[0] - gv[0], b1 = tv[1] - gv[1], b2 = tv[2] - gv[2];
+  float dis_vert = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  if (dis_vert < 0.005f) dis_vert = 0.0f;
+  float push_vert = 1.0f / (1.0f + 10.0f * dis_vert);
+  float ba[3] = {gv[0] - gb[0], gv[1] - gb[1], gv[2] - gb[2]}, ta[3] = {tv[0] - tb[0], tv[1] - tb[1], tv[2] - tb[2]};
+  float dotp = ba[0] * ta[0] + ba[1] * ta[1] + ba[2] * ta[2];
+  float nb = sqrtf(ba[0] * ba[0] + ba[1] * ba[1] + ba[2] * ba[2]), nt = sqrtf(ta[0] * ta[0] + ta[1] * ta[1] + ta[2] * ta[2]);
+  float c = dotp / (nb * nt);
+  c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);
+  float xita = acosf(c);
+  s->info_xita[e] = xita;
+  float push_w = 1.0f / (1.0f + 6.0f * xita);
+  float push_reward = (0.1515f * push_base + 0.1515f * push_vert + 0.66f * push_w) * W[0];
+  float old_newT[2] = {s->info_new_T_pos[2 * e], s->info_new_T_pos[2 * e + 1]};
+  float site_z_reward = sp[2] < 0.83f ? 1.0f : 0.0f;
+  float z_dis = fabsf(sp[2] - 0.805f);
+  float z_reward = 4.0f / (1.0f + 3.0f * z_dis);
+  site_z_reward = site_z_reward + z_reward;
+  float delta_x = ttail[0] - tail[0], delta_y = ttail[1] - tail[1];
+  float angle = atan2f(delta_y, delta_x + 0.00001f);
+  float distance = sqrtf(delta_x * delta_x + delta_y * delta_y) + 0.025f;
+  float y_ = distance * sinf(angle), x_ = distance * cosf(angle);
+  s->info_new_T_pos[2 * e] = delta_x - x_ + tail[0];
+  s->info_new_T_pos[2 * e + 1] = delta_y - y_ + tail[1];
+  float e0 = sp[0] - old_newT[0], e1 = sp[1] - old_newT[1];
+  float s2c = sqrtf(e0 * e0 + e1 * e1);
+  s2c = s2c < 0.02f ? 0.0f : s2c - 0.02f;
+  float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
+  float health = W[2] * fabsf((sp[2] < W[3] ? 1.0f : 0.0f) - 1.0f);
+  float reward = push_reward + siet + health + site_z_reward;
+  float done = s->xpos[e * m->nbody * 3 + 3 * id[TID_T] + 2] < 0.6f ? 1.0f : 0.0f;
+  reward = reward < -100.0f ? -100.0f : (reward > 100.0f ? 100.0f : reward);
+  tshape_obs(m, qpos, sp, gb, gv, tb, tv, xita, &s->info_new_T_pos[2 * e], &s->obs[e * m->obs_dim]);
+  float *met = &s->metrics[e * m->nmetrics];
+  met[0] = push_reward; met[1] = siet; met[2] = health; met[4] = site_z_reward;     /* task_complete_reward stays 0 */
+  for (int i = 0; i < 3; i++) { s->info_site_pos[3 * e + i] = sp[i]; s->info_T_pos[3 * e + i] = s->xpos[e * m->nbody * 3 + 3 * id[TID_T] + i]; }
+  s->reward[e] = reward; s->done[e] = done;
+  wrappers_post(m, s, e, reward);
+}
+
 /* ------------------------------------------------------------------ exported batch entry points */
 int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -1502,14 +1683,16 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 8)
 #endif
-    for (int e = 0; e < s->n; e++) reset_env(m, s, e, &keys[2 * e], d);
+    for (int e = 0; e < s->n; e++) {
+      if (m->env_kind == ENV_TSHAPE) tshape_reset_env(m, s, e, &keys[2 * e], d); else reset_env(m, s, e, &keys[2 * e], d);
+    }
     odata_free(d);
   }
   return 0;
 }
 
 int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -1519,7 +1702,9 @@ int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 8)
 #endif
-    for (int e = 0; e < s->n; e++) step_env(m, s, e, action, d);
+    for (int e = 0; e < s->n; e++) {
+      if (m->env_kind == ENV_TSHAPE) tshape_step_env(m, s, e, action, d); else step_env(m, s, e, action, d);
+    }
     odata_free(d);
   }
   return 0;

@@ -60,6 +60,7 @@ struct Layout {
   int qpos, qvel, ctrl, warm, time, xpos, site_xpos;
   int obs, reward, done, metrics;
   int target_pos, new_cube_pos, site_pos, cube_pos, last_action, steps, truncation, episode_done, episode_metrics;
+  int target_base_pos, target_vertical_pos, target_w, new_T_pos, T_pos, xita;     // T-shape env info
   int f_qpos, f_qvel, f_ctrl, f_warm, f_time, f_xpos, f_site_xpos, f_obs;
   int stats;
   int rec;            // floats per env (multiple of 16)
@@ -77,9 +78,10 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0>
 struct Dims {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
+  static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
   static constexpr int LD = NV_ + 1;                        // padded row stride: conflict-free row and column reads
   static constexpr int NEFC = NEQ_ + NF_ + NL_ + 6 * NCON_;   // constraint-row capacity (pyramid rows)
@@ -188,7 +190,7 @@ __device__ __forceinline__ unsigned long long prof_now() {
 constexpr int NSLOT = 16;                              // clip-scratch slots handed out to penetrating pairs
 template <class C>
 struct PhaseA {
-  float xquat[C::NB * 4], xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
+  float xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
   float xanchor[C::NJ * 3], xaxis[C::NJ * 3];
   float gpos[C::NG * 3], gmat[C::NG * 9];
   float cinert[C::NB * 10], crb[C::NB * 10];
@@ -204,7 +206,8 @@ struct Smem {
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
   float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
-  float xpos[C::NB * 3], spos[C::NS * 3];              // also read by the env epilogue
+  float xpos[C::NB * 3], xquat[C::NB * 4], spos[C::NS * 3];   // also read by the env epilogue
+  float egeom[(C::NEG > 0 ? C::NEG : 1) * 3];          // world positions of the env's geoms of interest
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
   float M[C::NV * C::LD], T[C::NV * C::LD];
   // contacts (active only)
@@ -267,7 +270,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
     if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
   }
   if (lane < C::NB) {
-    st3(&s.xpos[3 * b], pos); st4(&s.x.a.xquat[4 * b], q);
+    st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q);
     M33 R = q2m(q);
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.xmat[9 * b + c] = R.m[c];
@@ -282,7 +285,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
     if (m.jnt_type[j] == JNT_FREE) {
       st3(&s.x.a.xanchor[3 * j], ld3(&s.xpos[3 * jb])); st3(&s.x.a.xaxis[3 * j], v3(0, 0, 1));
     } else {
-      Q4 pq = ld4(&s.x.a.xquat[4 * jpar]);
+      Q4 pq = ld4(&s.xquat[4 * jpar]);
       Q4 qpre = qmul(pq, ld4(&m.body_quat[4 * jb]));
       V3 ppre = ld3(&s.xpos[3 * jpar]) + qrot(pq, ld3(&m.body_pos[3 * jb]));
       st3(&s.x.a.xanchor[3 * j], ppre + qrot(qpre, ld3(&m.jnt_pos[3 * j])));
@@ -291,7 +294,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
   }
   if (lane < C::NG) {
     int g = lane, gb = m.geom_bodyid[g];
-    Q4 gq = ld4(&s.x.a.xquat[4 * gb]);
+    Q4 gq = ld4(&s.xquat[4 * gb]);
     st3(&s.x.a.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.x.a.xmat[9 * gb], ld3(&m.geom_pos[3 * g])));
     M33 Rg = q2m(qmul(gq, ld4(&m.geom_quat[4 * g])));
 #pragma unroll
@@ -320,6 +323,7 @@ __device__ __forceinline__ void inert_mul(float* o, const float* i, const float*
 // =====================================================================================
 template <class C>
 __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
+  if (lane < C::NEG) st3(&s.egeom[3 * lane], ld3(&s.x.a.gpos[3 * m.env_ids[C::EG0 + lane]]));
   // subtree centre of mass: lane b sums its subtree
   if (lane < C::NB) {
     unsigned mask = m.body_submask[lane];

@@ -16,6 +16,8 @@ namespace rsr {
 
 // Airbot cube: nq 22, nv 20, nu 5, nbody 14, njnt 10, ngeom 23, nsite 1, npair 45, neq 1, nf 8, nl 8
 using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3>;
+// Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
+using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
 enum { ID_CUBE = 0, ID_TARGET = 1, ID_SITE = 2, ID_BOXQ = 3, ID_SITEQ = 4, ID_FINGERQ = 5, ID_JOINTQ = 6 };
@@ -78,6 +80,22 @@ __device__ void cube_obs(const DModel& m, const Smem<C>& s, const float* target_
   obs[15] = ncp[0]; obs[16] = ncp[1];
 }
 
+// T-shape env_ids layout (rsr_mjx_amd/envs/config.py: tshape_env_fields); egeom[0..3] = base_block, vertical_block,
+// base_target, vertical_target
+enum { TID_T = 0, TID_TARGET = 1, TID_SITE = 2, TID_TAIL = 3, TID_TTAIL = 4, TID_GBASE = 5, TID_JOINTQ = 9 };
+
+// T_shape_env.py:223-234
+template <class C>
+__device__ void tshape_obs(const DModel& m, const Smem<C>& s, const float* tb, const float* tv, float xita, const float* newT,
+                           float* obs) {
+  const int site = m.env_ids[TID_SITE];
+  for (int i = 0; i < 6; ++i) obs[i] = s.qpos[m.env_ids[TID_JOINTQ + i]];
+  obs[6] = s.spos[3 * site + 2];
+  for (int i = 0; i < 3; ++i) { obs[7 + i] = tb[i] - s.egeom[i]; obs[10 + i] = tv[i] - s.egeom[3 + i]; }
+  obs[13] = xita;
+  obs[14] = newT[0] - s.spos[3 * site]; obs[15] = newT[1] - s.spos[3 * site + 1];
+}
+
 template <class C>
 __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane, float warm, float time) {
   for (int t = lane; t < C::NQ; t += 64) rec[L.qpos + t] = s.qpos[t];
@@ -88,8 +106,9 @@ __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane
   for (int t = lane; t < C::NS * 3; t += 64) rec[L.site_xpos + t] = s.spos[t];
 }
 
-// ---------------------------------------------------------------- reset kernel (cube_env.py:95-143 + wrappers)
-template <class C>
+// ---------------------------------------------------------------- reset kernel
+// cube / sf: cube_env.py:95-143 ; T-shape: T_shape_env.py:98-137 ; + Episode/AutoReset wrapper resets
+template <class C, int ENV>
 __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -98,6 +117,8 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   if (e >= a.n) return;
   float* rec = a.state + (size_t)e * L.rec;
   const float* R = m.env_reset;
+  constexpr int JQ = ENV == ENV_TSHAPE ? (int)TID_JOINTQ : (int)ID_JOINTQ;     // arm joint qpos addresses in env_ids
+  constexpr int RCTRL = ENV == ENV_TSHAPE ? 7 : 8;                            // ctrl init in env_reset
   uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);         // PRNG scratch
   load_overrides<C>(m, s, a, e, lane);
   const uint32_t k0 = a.keys[2 * e], k1 = a.keys[2 * e + 1];
@@ -112,23 +133,25 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   WSYNC();
   if (lane < C::NQ) s.qpos[lane] = m.qpos0[lane] + uniform_from_bits(bits[lane], lo, hi);
   WSYNC();
-  if (lane < 6) s.qpos[m.env_ids[ID_JOINTQ + lane]] += R[1 + lane];
-  if (lane == 6) s.qpos[m.env_ids[ID_FINGERQ]] = R[7];
+  if (lane < 6) s.qpos[m.env_ids[JQ + lane]] += R[1 + lane];
+  if (ENV != ENV_TSHAPE && lane == 6) s.qpos[m.env_ids[ID_FINGERQ]] = R[7];
   random_bits(kk[2][0], kk[2][1], C::NV, bits, lane);
   WSYNC();
   if (lane < C::NV) s.qvel[lane] = uniform_from_bits(bits[lane], lo, hi);
   WSYNC();
   random_bits(kk[3][0], kk[3][1], C::NU, bits, lane);
   WSYNC();
-  float ctrl_init = lane < C::NU ? R[8 + lane] + uniform_from_bits(bits[lane], lo, hi) : 0.0f;
+  float ctrl_init = lane < C::NU ? R[RCTRL + lane] + uniform_from_bits(bits[lane], lo, hi) : 0.0f;
   WSYNC();
-  random_bits(kk[4][0], kk[4][1], 3, bits, lane);
-  WSYNC();
-  if (lane < 3) s.qpos[m.env_ids[ID_SITEQ] + lane] = uniform_from_bits(bits[lane], R[13 + lane], R[16 + lane]);
-  WSYNC();
-  random_bits(kk[0][0], kk[0][1], 3, bits, lane);
-  WSYNC();
-  if (lane < 3) s.qpos[m.env_ids[ID_BOXQ] + lane] = uniform_from_bits(bits[lane], R[19 + lane], R[22 + lane]);
+  if constexpr (ENV != ENV_TSHAPE) {
+    random_bits(kk[4][0], kk[4][1], 3, bits, lane);
+    WSYNC();
+    if (lane < 3) s.qpos[m.env_ids[ID_SITEQ] + lane] = uniform_from_bits(bits[lane], R[13 + lane], R[16 + lane]);
+    WSYNC();
+    random_bits(kk[0][0], kk[0][1], 3, bits, lane);
+    WSYNC();
+    if (lane < 3) s.qpos[m.env_ids[ID_BOXQ] + lane] = uniform_from_bits(bits[lane], R[19 + lane], R[22 + lane]);
+  }
   if (lane < C::NU) s.ctrl[lane] = 0.0f;                      // pipeline_init runs forward with ctrl = 0
   WSYNC();
   float Mrow[C::NV], warm = 0.0f;
@@ -139,18 +162,32 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   if (lane < C::NU) s.ctrl[lane] = ctrl_init;                 // data.replace(ctrl=joint_ctrl), no re-forward
   WSYNC();
   store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
-  const int cube = m.env_ids[ID_CUBE], tgt = m.env_ids[ID_TARGET], site = m.env_ids[ID_SITE];
   if (lane == 0) {
-    float tp[3], ncp[2] = {R[25], R[26]}, obs[C::OBS];
-    for (int i = 0; i < 3; ++i) {
-      tp[i] = s.xpos[3 * tgt + i];
-      rec[L.target_pos + i] = tp[i];
-      rec[L.site_pos + i] = s.spos[3 * site + i];
-      rec[L.cube_pos + i] = s.xpos[3 * cube + i];
+    float obs[C::OBS];
+    if constexpr (ENV == ENV_TSHAPE) {
+      const int site = m.env_ids[TID_SITE], tb = m.env_ids[TID_T];
+      float newT[2] = {R[12], R[13]};
+      for (int i = 0; i < 3; ++i) {
+        rec[L.target_base_pos + i] = s.egeom[6 + i]; rec[L.target_vertical_pos + i] = s.egeom[9 + i];
+        rec[L.site_pos + i] = s.spos[3 * site + i]; rec[L.T_pos + i] = s.xpos[3 * tb + i];
+      }
+      rec[L.target_w] = s.xquat[4 * m.env_ids[TID_TARGET]] * 10.0f;
+      rec[L.new_T_pos] = newT[0]; rec[L.new_T_pos + 1] = newT[1];
+      rec[L.xita] = R[14];
+      tshape_obs<C>(m, s, &s.egeom[6], &s.egeom[9], R[14], newT, obs);
+    } else {
+      const int cube = m.env_ids[ID_CUBE], tgt = m.env_ids[ID_TARGET], site = m.env_ids[ID_SITE];
+      float tp[3], ncp[2] = {R[25], R[26]};
+      for (int i = 0; i < 3; ++i) {
+        tp[i] = s.xpos[3 * tgt + i];
+        rec[L.target_pos + i] = tp[i];
+        rec[L.site_pos + i] = s.spos[3 * site + i];
+        rec[L.cube_pos + i] = s.xpos[3 * cube + i];
+      }
+      rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+      rec[L.last_action] = 0.0f;
+      cube_obs<C>(m, s, tp, ncp, obs);
     }
-    rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
-    rec[L.last_action] = 0.0f;
-    cube_obs<C>(m, s, tp, ncp, obs);
     for (int i = 0; i < C::OBS; ++i) { rec[L.obs + i] = obs[i]; rec[L.f_obs + i] = obs[i]; }
     rec[L.reward] = 0.0f; rec[L.done] = 0.0f;
     for (int i = 0; i < C::NMET; ++i) rec[L.metrics + i] = 0.0f;
@@ -168,13 +205,14 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   for (int t = lane; t < C::NS * 3; t += 64) rec[L.f_site_xpos + t] = s.spos[t];
 }
 
-// ---------------------------------------------------------------- step kernel (cube_env.py:145-213 + wrappers)
+// ---------------------------------------------------------------- step kernel
+// cube / sf: cube_env.py:145-213, test/airbot.py:165-252 ; T-shape: T_shape_env.py:139-221 ; + wrappers.
 // LDS is dynamic so that the register budget is set by RSR_WAVES_PER_EU below, not by the compiler's
 // LDS-derived occupancy guess (which lands one register over the 2-waves/SIMD budget and halves residency).
 #ifndef RSR_WAVES_PER_EU
 #define RSR_WAVES_PER_EU 2
 #endif
-template <class C>
+template <class C, int ENV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
 void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
@@ -184,7 +222,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   if (e >= a.n) return;
   float* rec = a.state + (size_t)e * L.rec;
   const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
-  const int cube = m.env_ids[ID_CUBE], site = m.env_ids[ID_SITE];
+  constexpr int JQ = ENV == ENV_TSHAPE ? (int)TID_JOINTQ : (int)ID_JOINTQ;
   PROF_DECL
   // ---- load the record ----
   for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
@@ -195,24 +233,38 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const float done_prev = rec[L.done];
   float steps = rec[L.steps];
   if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;     // AutoResetWrapper.step pre-step
-  float tp[3] = {rec[L.target_pos], rec[L.target_pos + 1], rec[L.target_pos + 2]};
-  float ncp_old[2] = {rec[L.new_cube_pos], rec[L.new_cube_pos + 1]};
-  // ---- prologue: ctrl shaping (cube_env.py:146-161); uses the stale xpos of the previous forward pass ----
+  // env info read before it is updated
+  float tp[3] = {0, 0, 0}, aux_old[2];
+  if constexpr (ENV == ENV_TSHAPE) { aux_old[0] = rec[L.new_T_pos]; aux_old[1] = rec[L.new_T_pos + 1]; }
+  else {
+    tp[0] = rec[L.target_pos]; tp[1] = rec[L.target_pos + 1]; tp[2] = rec[L.target_pos + 2];
+    aux_old[0] = rec[L.new_cube_pos]; aux_old[1] = rec[L.new_cube_pos + 1];
+  }
+  // ---- prologue: ctrl shaping; uses the stale xpos / site_xpos of the previous forward pass ----
   if (lane < C::NU) {
 #pragma clang fp contract(off)   // env algebra is evaluated op by op, as the reference's JAX-CPU path does
     float delta = m.env_action_scale[lane] * a.action[(size_t)e * C::NU + lane];
     float act = rec[L.ctrl + lane] + delta;
-    if (lane == 3) act = -((1.57f + rec[L.qpos + m.env_ids[ID_JOINTQ + 1]]) + rec[L.qpos + m.env_ids[ID_JOINTQ + 2]]);
+    if (lane == 3) act = -((1.57f + rec[L.qpos + m.env_ids[JQ + 1]]) + rec[L.qpos + m.env_ids[JQ + 2]]);
     float delta0 = m.env_action_scale[0] * a.action[(size_t)e * C::NU];
     float act0 = rec[L.ctrl] + delta0;
     if (lane == 4) {
-      float dx = tp[0] - rec[L.xpos + 3 * cube], dy = tp[1] - rec[L.xpos + 3 * cube + 1];
-      float ang = atan2f(dy, dx + 0.00001f);
-      act = (-ang + act0) + 1.5708f;
-      if (m.env_kind == ENV_AIRBOT_SF) {      // test/airbot.py:180-184: hold the wrist target within 3 cm of the goal
-        float dz = tp[2] - rec[L.xpos + 3 * cube + 2];
-        if (sqrtf(dx * dx + dy * dy + dz * dz) < 0.03f) act = rec[L.last_action];
-        rec[L.last_action] = act;
+      if constexpr (ENV == ENV_TSHAPE) {      // T_shape_env.py:146-153: aim from the end effector at the T's tail
+        const int site = m.env_ids[TID_SITE], tail = m.env_ids[TID_TAIL];
+        float dx = rec[L.site_xpos + 3 * tail] - rec[L.site_xpos + 3 * site];
+        float dy = rec[L.site_xpos + 3 * tail + 1] - rec[L.site_xpos + 3 * site + 1];
+        float ang = atan2f(dy, dx + 0.00001f);
+        act = (-ang + act0) + 1.5708f;
+      } else {                                // cube_env.py:152-159
+        const int cube = m.env_ids[ID_CUBE];
+        float dx = tp[0] - rec[L.xpos + 3 * cube], dy = tp[1] - rec[L.xpos + 3 * cube + 1];
+        float ang = atan2f(dy, dx + 0.00001f);
+        act = (-ang + act0) + 1.5708f;
+        if (m.env_kind == ENV_AIRBOT_SF) {    // test/airbot.py:180-184: hold the wrist target within 3 cm of the goal
+          float dz = tp[2] - rec[L.xpos + 3 * cube + 2];
+          if (sqrtf(dx * dx + dy * dy + dz * dz) < 0.03f) act = rec[L.last_action];
+          rec[L.last_action] = act;
+        }
       }
     }
     s.ctrl[lane] = clampf(act, m.env_ctrl_lo[lane], m.env_ctrl_hi[lane]);
@@ -232,40 +284,87 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     integrate<C>(m, s, lane, Mrow, f PROF_PASS);
     time += m.timestep;
   }
-  // ---- epilogue: reward, done, obs, info (cube_env.py:164-213); derived data are from the last forward ----
+  // ---- epilogue: reward, done, obs, info; derived data are from the last forward pass ----
   float done = 0.0f;
   float* obs_lds = s.T;                                     // staged so that auto-reset can override it
   if (lane == 0) {
 #pragma clang fp contract(off)
     const float* W = m.env_reward;
-    float cp[3] = {s.xpos[3 * cube], s.xpos[3 * cube + 1], s.xpos[3 * cube + 2]};
-    float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
-    float d0 = tp[0] - cp[0], d1 = tp[1] - cp[1], d2 = tp[2] - cp[2];
-    const bool sf = m.env_kind == ENV_AIRBOT_SF;
-    float btd = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    if (btd < W[4]) btd = 0.0f;                       // 0.005 (cube_env.py:166) / 0.003 (test/airbot.py:191)
-    float push = (1.0f / (1.0f + 3.0f * btd)) * W[0];
-    float task_complete = btd < W[4] ? W[5] : 0.0f;   // test/airbot.py:196
-    float site_z = sp[2] < 0.82f ? 1.0f : 0.0f;
-    float dx = tp[0] - cp[0], dy = tp[1] - cp[1];
-    float ang = atan2f(dy, dx + 0.00001f);
-    float dist = sqrtf(dx * dx + dy * dy) + 0.04f;
-    float y_ = dist * sinf(ang), x_ = dist * cosf(ang);
-    float ncp[2] = {dx - x_ + cp[0], dy - y_ + cp[1]};
-    float e0 = sp[0] - ncp_old[0], e1 = sp[1] - ncp_old[1];
-    float s2c = sqrtf(e0 * e0 + e1 * e1);
-    s2c = s2c < 0.042f ? 0.0f : s2c - 0.042f;
-    float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
-    if (btd < 0.005f) siet = W[1];
-    float hd = sp[2] < W[3] ? 1.0f : 0.0f;
-    if (sf && (sp[0] > 1.0f || sp[0] < -0.6f || sp[1] > 0.3f || sp[1] < -0.3f || cp[2] < 0.6f)) hd = 1.0f;   // test/airbot.py:227-233
-    float health = W[2] * fabsf(hd - 1.0f);
-    float reward = clampf(sf ? push + siet + health + task_complete + site_z : push + siet + health + site_z, -100.0f, 100.0f);
-    done = sf ? (btd < W[4] ? 1.0f : 0.0f) : (cp[2] < 0.6f ? 1.0f : 0.0f);
-    cube_obs<C>(m, s, tp, ncp, obs_lds);
-    rec[L.metrics + 0] = push; rec[L.metrics + 2] = siet;
-    for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.cube_pos + i] = cp[i]; }
-    rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+    float reward, met[C::NMET];
+    if constexpr (ENV == ENV_TSHAPE) {
+      const int site = m.env_ids[TID_SITE], tail = m.env_ids[TID_TAIL], ttail = m.env_ids[TID_TTAIL], tbody = m.env_ids[TID_T];
+      float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
+      const float* gb = &s.egeom[0]; const float* gv = &s.egeom[3];
+      float tb[3], tv[3];
+      for (int i = 0; i < 3; ++i) { tb[i] = rec[L.target_base_pos + i]; tv[i] = rec[L.target_vertical_pos + i]; }
+      float a0 = tb[0] - gb[0], a1 = tb[1] - gb[1], a2 = tb[2] - gb[2];
+      float dis_base = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+      if (dis_base < 0.005f) dis_base = 0.0f;
+      float push_base = 1.0f / (1.0f + 10.0f * dis_base);
+      float b0 = tv[0] - gv[0], b1 = tv[1] - gv[1], b2 = tv[2] - gv[2];
+      float dis_vert = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+      if (dis_vert < 0.005f) dis_vert = 0.0f;
+      float push_vert = 1.0f / (1.0f + 10.0f * dis_vert);
+      float ba[3] = {gv[0] - gb[0], gv[1] - gb[1], gv[2] - gb[2]}, ta[3] = {tv[0] - tb[0], tv[1] - tb[1], tv[2] - tb[2]};
+      float dotp = ba[0] * ta[0] + ba[1] * ta[1] + ba[2] * ta[2];
+      float nb = sqrtf(ba[0] * ba[0] + ba[1] * ba[1] + ba[2] * ba[2]), nt = sqrtf(ta[0] * ta[0] + ta[1] * ta[1] + ta[2] * ta[2]);
+      float xita = acosf(clampf(dotp / (nb * nt), -1.0f, 1.0f));
+      float push_w = 1.0f / (1.0f + 6.0f * xita);
+      float push = (0.1515f * push_base + 0.1515f * push_vert + 0.66f * push_w) * W[0];
+      float site_z = sp[2] < 0.83f ? 1.0f : 0.0f;
+      float z_reward = 4.0f / (1.0f + 3.0f * fabsf(sp[2] - 0.805f));
+      site_z = site_z + z_reward;
+      float tx = s.spos[3 * tail], ty = s.spos[3 * tail + 1];
+      float dx = s.spos[3 * ttail] - tx, dy = s.spos[3 * ttail + 1] - ty;
+      float ang = atan2f(dy, dx + 0.00001f);
+      float dist = sqrtf(dx * dx + dy * dy) + 0.025f;
+      float y_ = dist * sinf(ang), x_ = dist * cosf(ang);
+      float newT[2] = {dx - x_ + tx, dy - y_ + ty};
+      float e0 = sp[0] - aux_old[0], e1 = sp[1] - aux_old[1];
+      float s2c = sqrtf(e0 * e0 + e1 * e1);
+      s2c = s2c < 0.02f ? 0.0f : s2c - 0.02f;
+      float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
+      float health = W[2] * fabsf((sp[2] < W[3] ? 1.0f : 0.0f) - 1.0f);
+      reward = clampf(push + siet + health + site_z, -100.0f, 100.0f);
+      done = s.xpos[3 * tbody + 2] < 0.6f ? 1.0f : 0.0f;
+      tshape_obs<C>(m, s, tb, tv, xita, newT, obs_lds);
+      met[0] = push; met[1] = siet; met[2] = health; met[3] = rec[L.metrics + 3]; met[4] = site_z;
+      rec[L.metrics + 0] = push; rec[L.metrics + 1] = siet; rec[L.metrics + 2] = health; rec[L.metrics + 4] = site_z;
+      for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.T_pos + i] = s.xpos[3 * tbody + i]; }
+      rec[L.new_T_pos] = newT[0]; rec[L.new_T_pos + 1] = newT[1];
+      rec[L.xita] = xita;
+    } else {
+      const int cube = m.env_ids[ID_CUBE], site = m.env_ids[ID_SITE];
+      float cp[3] = {s.xpos[3 * cube], s.xpos[3 * cube + 1], s.xpos[3 * cube + 2]};
+      float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
+      float d0 = tp[0] - cp[0], d1 = tp[1] - cp[1], d2 = tp[2] - cp[2];
+      const bool sf = m.env_kind == ENV_AIRBOT_SF;
+      float btd = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+      if (btd < W[4]) btd = 0.0f;                       // 0.005 (cube_env.py:166) / 0.003 (test/airbot.py:191)
+      float push = (1.0f / (1.0f + 3.0f * btd)) * W[0];
+      float task_complete = btd < W[4] ? W[5] : 0.0f;   // test/airbot.py:196
+      float site_z = sp[2] < 0.82f ? 1.0f : 0.0f;
+      float dx = tp[0] - cp[0], dy = tp[1] - cp[1];
+      float ang = atan2f(dy, dx + 0.00001f);
+      float dist = sqrtf(dx * dx + dy * dy) + 0.04f;
+      float y_ = dist * sinf(ang), x_ = dist * cosf(ang);
+      float ncp[2] = {dx - x_ + cp[0], dy - y_ + cp[1]};
+      float e0 = sp[0] - aux_old[0], e1 = sp[1] - aux_old[1];
+      float s2c = sqrtf(e0 * e0 + e1 * e1);
+      s2c = s2c < 0.042f ? 0.0f : s2c - 0.042f;
+      float siet = (1.0f - tanhf(5.0f * s2c)) * W[1];
+      if (btd < 0.005f) siet = W[1];
+      float hd = sp[2] < W[3] ? 1.0f : 0.0f;
+      if (sf && (sp[0] > 1.0f || sp[0] < -0.6f || sp[1] > 0.3f || sp[1] < -0.3f || cp[2] < 0.6f)) hd = 1.0f;   // test/airbot.py:227-233
+      float health = W[2] * fabsf(hd - 1.0f);
+      reward = clampf(sf ? push + siet + health + task_complete + site_z : push + siet + health + site_z, -100.0f, 100.0f);
+      done = sf ? (btd < W[4] ? 1.0f : 0.0f) : (cp[2] < 0.6f ? 1.0f : 0.0f);
+      cube_obs<C>(m, s, tp, ncp, obs_lds);
+      met[0] = push; met[1] = rec[L.metrics + 1]; met[2] = siet;
+      rec[L.metrics + 0] = push; rec[L.metrics + 2] = siet;
+      for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.cube_pos + i] = cp[i]; }
+      rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
+    }
     rec[L.reward] = reward;
     // EpisodeWrapper.step (action_repeat = 1)
     if (wrap_episode) {
@@ -276,7 +375,6 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
       float* em = rec + L.episode_metrics;
       em[0] = (em[0] + reward) * (1.0f - prev_done);
       em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
-      float met[3] = {push, rec[L.metrics + 1], siet};
       for (int i = 0; i < C::NMET; ++i) em[2 + i] = (em[2 + i] + met[i]) * (1.0f - prev_done);
       if (over) done = 1.0f;
       rec[L.episode_done] = done;
@@ -361,6 +459,8 @@ static Layout make_layout(const rsr_dims& d) {
   L.obs = take(d.obs_dim); L.f_obs = take(d.obs_dim);
   L.reward = take(1); L.done = take(1); L.metrics = take(d.nmetrics);
   L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3); L.last_action = take(1);
+  L.target_base_pos = take(3); L.target_vertical_pos = take(3); L.target_w = take(1); L.new_T_pos = take(2);
+  L.T_pos = take(3); L.xita = take(1);
   L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
   L.stats = take(4);
   L.rec = (o + 15) & ~15;
@@ -382,12 +482,16 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   d.nq = dims[0]; d.nv = dims[1]; d.nu = dims[2]; d.nbody = dims[3]; d.njnt = dims[4]; d.ngeom = dims[5];
   d.nsite = dims[6]; d.neq = dims[7]; d.npair = dims[8];
   d.env_kind = ei[0]; d.n_frames = ei[1]; d.episode_length = ei[2]; d.obs_dim = ei[4]; d.nmetrics = ei[5];
-  using C = rsr::CubeDims;
   const int* c2 = static_cast<const int*>(m->find("counts2"));
-  bool ok = (d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) && d.nq == C::NQ && d.nv == C::NV && d.nu == C::NU && d.nbody == C::NB &&
-            d.njnt == C::NJ && d.ngeom == C::NG && d.nsite == C::NS && d.npair == C::NP && d.neq == C::NEQ && c2 &&
-            c2[0] == C::NF && c2[1] == C::NL && d.obs_dim == C::OBS && d.nmetrics == C::NMET;
-  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf)"); }
+  auto fits = [&](auto dims_tag) {
+    using C = decltype(dims_tag);
+    return d.nq == C::NQ && d.nv == C::NV && d.nu == C::NU && d.nbody == C::NB && d.njnt == C::NJ && d.ngeom == C::NG &&
+           d.nsite == C::NS && d.npair == C::NP && d.neq == C::NEQ && c2 && c2[0] == C::NF && c2[1] == C::NL &&
+           d.obs_dim == C::OBS && d.nmetrics == C::NMET;
+  };
+  bool ok = ((d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) && fits(rsr::CubeDims{})) ||
+            (d.env_kind == rsr::ENV_TSHAPE && fits(rsr::TShapeDims{}));
+  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape)"); }
   if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
   for (int i = 0; i < npc; ++i) if (pc[i] != 4) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: only condim-4 contact pairs are built"); }
@@ -395,7 +499,8 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   for (int i = 0; i < nea; ++i) if (!ea[i]) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: inactive equality constraints are not built"); }
   if (static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_IMPLICITFAST &&
       static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: integrator"); }
-  d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>);
+  if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
+  else { using C = rsr::CubeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   m->layout = make_layout(d);
   d.rec_floats = m->layout.rec;
   *out = m;
@@ -510,8 +615,13 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.keys = keys;
-  hipLaunchKernelGGL(rsr::reset_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), static_cast<hipStream_t>(hip_stream), b->dmodel,
-                     b->model->layout, a);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
+    hipLaunchKernelGGL((rsr::reset_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
+                       b->dmodel, b->model->layout, a);
+  else
+    hipLaunchKernelGGL((rsr::reset_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
+                       b->dmodel, b->model->layout, a);
   HIPCHK(hipGetLastError());
   return RSR_OK;
 }
@@ -521,8 +631,13 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   HIPCHK(hipSetDevice(b->device));
   rsr::StepArgs a = make_args(b);
   a.action = action;
-  hipLaunchKernelGGL(rsr::step_kernel<rsr::CubeDims>, dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), static_cast<hipStream_t>(hip_stream), b->dmodel,
-                     b->model->layout, a);
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
+    hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
+                       b->dmodel, b->model->layout, a);
+  else
+    hipLaunchKernelGGL((rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
+                       b->dmodel, b->model->layout, a);
   HIPCHK(hipGetLastError());
   if (b->timing) b->launches++;
   return RSR_OK;
@@ -550,6 +665,12 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_INFO_SITE_POS: off = L.site_pos; w = 3; break;
     case RSR_F_INFO_CUBE_POS: off = L.cube_pos; w = 3; break;
     case RSR_F_INFO_LAST_ACTION: off = L.last_action; w = 1; break;
+    case RSR_F_INFO_TARGET_BASE_POS: off = L.target_base_pos; w = 3; break;
+    case RSR_F_INFO_TARGET_VERTICAL_POS: off = L.target_vertical_pos; w = 3; break;
+    case RSR_F_INFO_TARGET_W: off = L.target_w; w = 1; break;
+    case RSR_F_INFO_NEW_T_POS: off = L.new_T_pos; w = 2; break;
+    case RSR_F_INFO_T_POS: off = L.T_pos; w = 3; break;
+    case RSR_F_INFO_XITA: off = L.xita; w = 1; break;
     case RSR_F_INFO_STEPS: off = L.steps; w = 1; break;
     case RSR_F_INFO_TRUNCATION: off = L.truncation; w = 1; break;
     case RSR_F_INFO_EPISODE_DONE: off = L.episode_done; w = 1; break;

@@ -69,6 +69,8 @@ class AirbotPlayBase:
     _default_asset = "airbot_cube.npz"
     _fields_fn = staticmethod(cfg.cube_env_fields)
     _defaults = cfg.CUBE_DEFAULTS
+    _obs_dim = cfg.CUBE_OBS_DIM
+    _metrics = cfg.CUBE_METRICS
 
     def __init__(self, model_path: Optional[str] = None, device: str = "cuda:0", **kwargs):
         if model_path is None:
@@ -86,7 +88,7 @@ class AirbotPlayBase:
     # --- reference properties ---
     @property
     def observation_size(self) -> int:
-        return cfg.CUBE_OBS_DIM
+        return self._obs_dim
 
     @property
     def action_size(self) -> int:
@@ -126,6 +128,17 @@ class AirbotPlaySF(AirbotPlayBase):
     _default_asset = "airbot_sf.npz"
     _fields_fn = staticmethod(cfg.sf_env_fields)
     _defaults = cfg.SF_DEFAULTS
+
+
+class AirbotTShape(AirbotPlayBase):
+    """T-block pushing task (reference ppo_train/airbot_training/T_shape_env.py, model T_shape.xml):
+    16-dim obs, angle term `xita`, two geom-distance rewards."""
+
+    _default_asset = "airbot_tshape.npz"
+    _fields_fn = staticmethod(cfg.tshape_env_fields)
+    _defaults = cfg.TSHAPE_DEFAULTS
+    _obs_dim = cfg.TSHAPE_OBS_DIM
+    _metrics = cfg.TSHAPE_METRICS
 
 
 class BatchedEnv:
@@ -234,12 +247,18 @@ class BatchedEnv:
         ps = PipelineState(qpos=v["qpos"], qvel=v["qvel"], ctrl=v["ctrl"], qacc_warmstart=v["qacc_warmstart"],
                            time=v["time"][:, 0], xpos=v["xpos"].unflatten(1, (self.dims.nbody, 3)),
                            site_xpos=v["site_xpos"].unflatten(1, (self.dims.nsite, 3)))
-        metrics = {name: v["metrics"][:, i] for i, name in enumerate(cfg.CUBE_METRICS)}
-        info = {
-            "target_pos": v["info_target_pos"], "new_cube_pos": v["info_new_cube_pos"],
-            "site_pos": v["info_site_pos"], "cube_pos": v["info_cube_pos"],
-            "reached_box": self.record.new_zeros((n,)),
-        }
+        mnames = self.env._metrics
+        metrics = {name: v["metrics"][:, i] for i, name in enumerate(mnames)}
+        if isinstance(self.env, AirbotTShape):     # T_shape_env.py:127-134
+            info = {"target_base_pos": v["info_target_base_pos"], "target_vertical_pos": v["info_target_vertical_pos"],
+                    "target_w": v["info_target_w"][:, 0], "new_T_pos": v["info_new_T_pos"], "site_pos": v["info_site_pos"],
+                    "T_pos": v["info_T_pos"], "xita": v["info_xita"][:, 0]}
+        else:                                      # cube_env.py:135-140
+            info = {
+                "target_pos": v["info_target_pos"], "new_cube_pos": v["info_new_cube_pos"],
+                "site_pos": v["info_site_pos"], "cube_pos": v["info_cube_pos"],
+                "reached_box": self.record.new_zeros((n,)),
+            }
         if isinstance(self.env, AirbotPlaySF):
             info["last_action"] = v["info_last_action"][:, 0]
         if self.episode_length > 0:
@@ -247,7 +266,7 @@ class BatchedEnv:
             info.update(steps=v["info_steps"][:, 0], truncation=v["info_truncation"][:, 0],
                         episode_done=v["info_episode_done"][:, 0],
                         episode_metrics={"sum_reward": em[:, 0], "length": em[:, 1],
-                                         **{name: em[:, 2 + i] for i, name in enumerate(cfg.CUBE_METRICS)}})
+                                         **{name: em[:, 2 + i] for i, name in enumerate(mnames)}})
         if self.auto_reset:
             info.update(first_obs=v["first_obs"],
                         first_pipeline_state=PipelineState(

@@ -78,3 +78,43 @@ def cube_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool 
         env_reset=reset,
         env_reward=reward,
     )
+
+
+# ---------------------------------------------------------------------------------------------------------
+# T-shape task: reference ppo_train/airbot_training/T_shape_env.py:11-97 (constructor), :98-137 (reset constants)
+TSHAPE_DEFAULTS = dict(CUBE_DEFAULTS, push_reward_weight=10.0, endpoint_min_z_pos=0.78)
+TSHAPE_OBS_DIM = 16
+TSHAPE_METRICS = ("push_reward", "siet2cube_reward", "health_reward", "task_complete_reward", "site_z_reward")
+
+
+def tshape_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: bool = False, **kwargs) -> Dict[str, np.ndarray]:
+    cfg = dict(TSHAPE_DEFAULTS)
+    n_frames = kwargs.pop("n_frames", None)
+    unknown = set(kwargs) - set(cfg)
+    if unknown:
+        raise TypeError(f"unknown AirbotPlayBase (T-shape) arguments: {sorted(unknown)}")
+    cfg.update(kwargs)
+    if n_frames is None:
+        n_frames = cfg["decimation"]
+    A = m.arrays
+    jq = [int(A["jnt_qposadr"][m.id("joint", f"joint{i}")]) for i in range(1, 7)]
+    ids = np.array([m.id("body", "T_block"), m.id("body", "T_target"), m.id("site", "endpoint"), m.id("site", "T_tail"),
+                    m.id("site", "T_target_tail"), m.id("geom", "base_block"), m.id("geom", "vertical_block"),
+                    m.id("geom", "base_target"), m.id("geom", "vertical_target")] + jq, dtype=np.int32)
+    flags = (WRAP_EPISODE if episode_length > 0 else 0) | (WRAP_AUTORESET if auto_reset else 0)
+    reset = np.array([cfg["noise_scale"],
+                      0, -0.57303354, 0.381795, 1.5718, -1.3787, 1.1731174,     # T_shape_env.py:105
+                      0, -0.57303354, 0.381795, -1.3787, 1.1731174,             # :109
+                      0.24739072, -0.00496255,                                   # :116
+                      0.2876], dtype=np.float32)                                 # :132
+    reward = np.array([cfg["push_reward_weight"], cfg["siet_to_box_reward_weight"], cfg["healthy_reward"],
+                       cfg["endpoint_min_z_pos"]], dtype=np.float32)
+    return dict(
+        env_int=np.array([ENV_TSHAPE, n_frames, episode_length, flags, TSHAPE_OBS_DIM, len(TSHAPE_METRICS)], dtype=np.int32),
+        env_ids=ids,
+        env_action_scale=np.array([0.02, 0.02, 0.02, 0.0, 0.0], dtype=np.float32),
+        env_ctrl_lo=A["actuator_ctrlrange"][:, 0].astype(np.float32),
+        env_ctrl_hi=A["actuator_ctrlrange"][:, 1].astype(np.float32),
+        env_reset=reset,
+        env_reward=reward,
+    )

@@ -424,6 +424,12 @@ class MjcfCompiler:
     def _body_inertial(self, b: _Body):
         """Returns (mass, ipos, iquat, diaginertia) in the body frame."""
         use_geoms = (self.inertiafromgeom == "true") or (self.inertiafromgeom == "auto" and b.inertial is None)
+        if use_geoms:
+            # MuJoCo only overrides the <inertial> element when the body has geoms in the inertia group range
+            has = any(self.inertiagrouprange[0] <= int(g.get("group", 0)) <= self.inertiagrouprange[1]
+                      and _GEOM_TYPES[g.get("type", "sphere")] not in (GEOM_PLANE, GEOM_HFIELD, GEOM_MESH) for g in b.geoms)
+            if not has and b.inertial is not None:
+                use_geoms = False
         if not use_geoms:
             if b.inertial is None:
                 return 0.0, np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3)

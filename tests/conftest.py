@@ -37,11 +37,17 @@ def sf_model():
     return CompiledModel.load(os.path.join(ASSETS, "airbot_sf.npz"))
 
 
+@pytest.fixture(scope="session")
+def tshape_model():
+    from rsr_mjx_amd.mjcf import CompiledModel
+    return CompiledModel.load(os.path.join(ASSETS, "airbot_tshape.npz"))
+
+
 def make_blob(model, kind="cube", **env_kwargs):
     from rsr_mjx_amd.envs import config
     from rsr_mjx_amd.model import model_fields, pack_blob
     f = model_fields(model)
-    f.update({"cube": config.cube_env_fields, "sf": config.sf_env_fields}[kind](model, **env_kwargs))
+    f.update({"cube": config.cube_env_fields, "sf": config.sf_env_fields, "tshape": config.tshape_env_fields}[kind](model, **env_kwargs))
     return pack_blob(f)
 
 

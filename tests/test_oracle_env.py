@@ -250,3 +250,70 @@ def test_sf_variant_follows_test_airbot_py(sf_model, oracle_mod):
         np.testing.assert_array_equal(st["done"], (btd < f(0.003)).astype(f))
         if t == 10:
             assert st["done"][: n // 2].min() == 1.0 and np.all(st["reward"][: n // 2] >= 6 + 3 + 5)
+
+
+def test_tshape_env_follows_T_shape_env_py(tshape_model, oracle_mod):
+    """reference T_shape_env.py: reset :98-137, ctrl shaping :146-153 (aim at site T_tail), rewards :158-200, obs :223-234,
+    restated in numpy from the source text."""
+    f = np.float32
+    m = tshape_model
+    assert (m.nq, m.nv, m.nbody, m.ngeom, m.nsite, m.npair) == (15, 14, 14, 25, 3, 60)
+    np.testing.assert_allclose(m.arrays["body_mass"][13], 0.625, rtol=1e-12)       # inertiafromgeom: 0.375 + 0.25 kg
+    orc = oracle_mod.Oracle(make_blob(m, kind="tshape"))
+    n = 32
+    st = orc.new_state(n)
+    keys = prng.split(prng.PRNGKey(13), n)
+    orc.reset(st, keys)
+    for e in range(4):
+        ks = prng.split(keys[e], 5)
+        q = m.arrays["qpos0"].astype(f) + prng.uniform(ks[1], (15,), -0.01, 0.01)
+        q[:6] += np.array([0, -0.57303354, 0.381795, 1.5718, -1.3787, 1.1731174], f)
+        q[11:15] /= np.linalg.norm(q[11:15])
+        np.testing.assert_allclose(st["qpos"][e], q, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(st["ctrl"][e], np.array([0, -0.57303354, 0.381795, -1.3787, 1.1731174], f) + prng.uniform(ks[3], (5,), -0.01, 0.01))
+    np.testing.assert_allclose(st["info_target_w"], 10 * np.cos(0.785398163 / 2), rtol=1e-6)    # xquat[T_target][0] * 10
+    assert np.all(st["info_xita"] == f(0.2876)) and np.all(st["obs"][:, 13] == f(0.2876))
+    np.testing.assert_array_equal(st["info_new_T_pos"], np.tile(f([0.24739072, -0.00496255]), (n, 1)))
+    rng = np.random.default_rng(13)
+    for t in range(20):
+        pre = _snap(st)
+        a = rng.uniform(-1, 1, (n, 5)).astype(f)
+        orc.step(st, a)
+        # prologue
+        act0 = pre["ctrl"][:, 0] + f(0.02) * a[:, 0]
+        dx = pre["site_xpos"][:, 2, 0] - pre["site_xpos"][:, 0, 0]
+        dy = pre["site_xpos"][:, 2, 1] - pre["site_xpos"][:, 0, 1]
+        want4 = (-np.arctan2(dy, dx + f(0.00001)).astype(f) + act0) + f(1.5708)
+        np.testing.assert_allclose(st["ctrl"][:, 4], np.clip(want4, -3.14, 3.14), rtol=1e-6, atol=1e-6)
+        # epilogue pieces that only need record fields: obs layout and reward decomposition
+        sp = st["site_xpos"][:, 0]
+        np.testing.assert_array_equal(st["obs"][:, :6], st["qpos"][:, :6])
+        np.testing.assert_array_equal(st["obs"][:, 6], sp[:, 2])
+        np.testing.assert_array_equal(st["obs"][:, 13], st["info_xita"])
+        np.testing.assert_allclose(st["obs"][:, 14:16], st["info_new_T_pos"] - sp[:, :2], rtol=1e-6, atol=1e-7)
+        tail, ttail = st["site_xpos"][:, 2], st["site_xpos"][:, 1]
+        ddx, ddy = ttail[:, 0] - tail[:, 0], ttail[:, 1] - tail[:, 1]
+        ang = np.arctan2(ddy, ddx + f(0.00001)).astype(f)
+        dist = np.sqrt(ddx * ddx + ddy * ddy).astype(f) + f(0.025)
+        newT = np.stack([ddx - dist * np.cos(ang).astype(f) + tail[:, 0], ddy - dist * np.sin(ang).astype(f) + tail[:, 1]], -1)
+        np.testing.assert_allclose(st["info_new_T_pos"], newT, rtol=2e-6, atol=2e-6)
+        gb = pre["info_target_base_pos"] - st["obs"][:, 7:10]          # geom_xpos[base_block] recovered from the obs
+        gv = pre["info_target_vertical_pos"] - st["obs"][:, 10:13]
+        ba, ta = gv - gb, pre["info_target_vertical_pos"] - pre["info_target_base_pos"]
+        c = (ba * ta).sum(-1) / (np.linalg.norm(ba, axis=-1) * np.linalg.norm(ta, axis=-1))
+        np.testing.assert_allclose(st["info_xita"], np.arccos(np.clip(c, -1, 1)), rtol=1e-3, atol=2e-4)
+        xita = st["info_xita"]
+        db = np.linalg.norm(st["obs"][:, 7:10], axis=-1); db = np.where(db < 0.005, 0, db)
+        dv = np.linalg.norm(st["obs"][:, 10:13], axis=-1); dv = np.where(dv < 0.005, 0, dv)
+        push = (0.1515 / (1 + 10 * db) + 0.1515 / (1 + 10 * dv) + 0.66 / (1 + 6 * xita)) * 10.0
+        np.testing.assert_allclose(st["metrics"][:, 0], push, rtol=1e-5)
+        s2c = np.linalg.norm(sp[:, :2] - pre["info_new_T_pos"], axis=-1)
+        s2c = np.where(s2c < 0.02, 0, s2c - 0.02)
+        siet = (1 - np.tanh(5 * s2c)) * 3.0
+        np.testing.assert_allclose(st["metrics"][:, 1], siet, rtol=1e-5, atol=1e-6)
+        health = np.abs((sp[:, 2] < 0.78).astype(f) - 1)
+        site_z = (sp[:, 2] < 0.83).astype(f) + 4.0 / (1 + 3 * np.abs(sp[:, 2] - 0.805))
+        np.testing.assert_allclose(st["metrics"][:, 4], site_z, rtol=1e-5)
+        np.testing.assert_allclose(st["reward"], np.clip(push + siet + health + site_z, -100, 100), rtol=1e-5)
+        assert np.all(st["metrics"][:, 3] == 0)
+        np.testing.assert_array_equal(st["done"], (st["xpos"][:, 13, 2] < 0.6).astype(f))

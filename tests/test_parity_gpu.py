@@ -31,8 +31,11 @@ def _check_strict(env, st, st64=None, fields=STRICT, tag=""):
     """>= 99 % of the envs within 1e-5; the rest bounded by the fp32 oracle's own distance to fp64."""
     for k in fields:
         err = _scaled_err(_np(env, k, st[k]), st[k])
-        bound = 1e-4 + (3.0 * _scaled_err(st[k], st64[k]).max() if st64 is not None else 0.0)
-        assert np.sum(err > 1e-5) <= max(1, int(0.01 * len(err))), (tag, k, int(np.sum(err > 1e-5)), len(err))
+        e_cpu = _scaled_err(st[k], st64[k]) if st64 is not None else np.zeros(1)
+        bound = 1e-4 + 3.0 * e_cpu.max()
+        # outliers: at most 1 % of the envs, or twice as many as the fp32 oracle itself has against its fp64 build
+        allowed = max(1, int(0.01 * len(err)), int(2.0 * np.sum(e_cpu > 1e-5)))
+        assert np.sum(err > 1e-5) <= allowed, (tag, k, int(np.sum(err > 1e-5)), allowed, len(err))
         assert err.max() <= bound, (tag, k, float(err.max()), bound)
 SHARED = STRICT + EXACT + SOLVER + ["info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
                            "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs"]
@@ -175,6 +178,47 @@ def test_sf_variant_parity(setup, oracle_mod):
         for k in EXACT:
             np.testing.assert_array_equal(_np(env, k, st[k]), st[k], err_msg=f"{k} at step {t}")
     assert "last_action" in state.info
+
+
+def test_tshape_parity(setup, oracle_mod):
+    """BASELINE configs[2] model (T_shape.xml: 60 geom pairs, dt 2.5e-4, 8 Newton iterations): reset + teacher-forced steps."""
+    import torch
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.envs.airbot import AirbotTShape
+    n = 256
+    env = AirbotTShape(device="cuda:0").batched(n, episode_length=1000, auto_reset=True)
+    assert env.observation_size == 16 and env.dims.nv == 14 and env.dims.npair == 60
+    orc = oracle_mod.Oracle(env.blob)
+    orc.set_ncon_cap(env.dims.ncon_max)
+    orc64 = oracle_mod.Oracle(env.blob, "f64")
+    orc64.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(31), n)
+    st = orc.new_state(n)
+    orc.reset(st, keys)
+    state = env.reset(keys)
+    torch.cuda.synchronize()
+    tfields = ["info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita"]
+    common = [k for k in SHARED if not k.startswith("info_target_pos") and k not in ("info_new_cube_pos", "info_cube_pos")]
+    for k in ["qpos", "xpos", "site_xpos", "obs", "first_obs"] + tfields:
+        assert _scaled_err(_np(env, k, st[k]), st[k]).max() <= 1e-5, k
+    rng = np.random.default_rng(31)
+    for depth in (0, 9, 40):
+        for _ in range(depth):
+            orc.step(st, np.clip(rng.normal(size=(n, 5)), -1, 1).astype(np.float32))
+        for k in common + tfields:
+            env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        st64 = {k: (v.copy() if v is not None else None) for k, v in st.items()}
+        act = np.clip(rng.normal(size=(n, 5)), -1, 1).astype(np.float32)
+        orc.step(st, act); orc64.step(st64, act)
+        state = env.step(state, act)
+        torch.cuda.synchronize()
+        assert int(env.view("stats")[:, 3].sum()) == 0
+        _check_strict(env, st, st64, fields=["obs", "reward", "metrics", "xpos", "site_xpos", "qpos", "ctrl", "info_xita", "info_new_T_pos", "info_T_pos"],
+                      tag=f"tshape depth {depth}")
+        for k in EXACT:
+            np.testing.assert_array_equal(_np(env, k, st[k]), st[k], err_msg=k)
+    assert set(state.info) >= {"target_base_pos", "target_vertical_pos", "target_w", "new_T_pos", "site_pos", "T_pos", "xita"}
+    assert set(state.metrics) == {"push_reward", "siet2cube_reward", "health_reward", "task_complete_reward", "site_z_reward"}
 
 
 def test_golden_fixture_configs0(setup):

@@ -6,13 +6,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from oracle import oracle as O
 from rsr_mjx_amd import prng
-from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
+from rsr_mjx_amd.envs.airbot import AirbotPlayBase, AirbotTShape, domain_randomize
 from test_parity_gpu import _np, _push, _scaled_err
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    envdef = AirbotPlayBase()
-    dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(5), n))
+    tshape = len(sys.argv) > 2 and sys.argv[2] == "tshape"
+    envdef = AirbotTShape() if tshape else AirbotPlayBase()
+    dr = None if tshape else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(5), n))
     env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
     orc = O.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
     o64 = O.Oracle(env.blob, "f64"); o64.set_ncon_cap(env.dims.ncon_max)
@@ -22,7 +23,12 @@ def main():
     for depth in (0, 7, 53):
         for _ in range(depth):
             orc.step(st, np.clip(rng.normal(size=(n, 5)), -1, 1).astype(np.float32))
-        _push(env, st)
+        if tshape:
+            for k in st:
+                if k in env._views and st[k] is not None and k != "stats":
+                    env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        else:
+            _push(env, st)
         st64 = {k: (v.copy() if v is not None else None) for k, v in st.items()}
         act = np.clip(rng.normal(size=(n, 5)), -1, 1).astype(np.float32)
         orc.step(st, act); o64.step(st64, act); env.step(None, act); torch.cuda.synchronize()
