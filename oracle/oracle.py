@@ -20,6 +20,7 @@ _BATCH_FIELDS = [
     "info_target_pos", "info_new_cube_pos", "info_site_pos", "info_cube_pos", "info_last_action",
     "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics",
     "info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita",
+    "info_go2",
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
     "first_obs",
     "dr_geom_friction", "dr_body_mass", "dr_dof_damping", "dr_dof_frictionloss",
@@ -93,7 +94,7 @@ class Oracle:
             obs=z(self.obs_dim), reward=z(), done=z(), metrics=z(self.nmetrics),
             info_target_pos=z(3), info_new_cube_pos=z(2), info_site_pos=z(3), info_cube_pos=z(3), info_last_action=z(),
             info_steps=z(), info_truncation=z(), info_episode_done=z(), info_episode_metrics=z(2 + self.nmetrics),
-            info_target_base_pos=z(3), info_target_vertical_pos=z(3), info_target_w=z(), info_new_T_pos=z(2), info_T_pos=z(3), info_xita=z(),
+            info_target_base_pos=z(3), info_target_vertical_pos=z(3), info_target_w=z(), info_new_T_pos=z(2), info_T_pos=z(3), info_xita=z(), info_go2=z(144),
             first_qpos=z(self.nq), first_qvel=z(self.nv), first_ctrl=z(self.nu), first_warmstart=z(self.nv),
             first_time=z(), first_xpos=z(self.nbody, 3), first_site_xpos=z(self.nsite, 3), first_obs=z(self.obs_dim),
             stats=np.zeros((n, 4), dtype=np.int32),

@@ -48,10 +48,12 @@ enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
 #define NJNT_MAX 16
 #define NGEOM_MAX 40
 #define NSITE_MAX 8
+#define NKEY_MAX 8
 #define NPAIR_MAX 64
 #define NCON_MAX (NPAIR_MAX * 4)
 #define NEFC_MAX (1 + 2 * NV_MAX + 6 * NCON_MAX)
 #define OBS_MAX 64
+#define GO2_INFO 144
 
 /* ------------------------------------------------------------------ blob */
 typedef struct { char name[40]; int32_t dtype, count, offset, reserved; } blob_entry;
@@ -95,6 +97,8 @@ typedef struct {
   int env_kind, n_frames, episode_length, wrap_flags, obs_dim, nmetrics;
   const int *env_ids;
   const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
+  const float *env_go2f, *env_go2_scales, *env_go2_home, *env_go2_soft;
+  const int *env_go2i;
   void *blob_copy;
 } omodel;
 
@@ -144,6 +148,7 @@ omodel *oracle_model_create(const void *blob, int nbytes) {
     m->obs_dim = ei[4]; m->nmetrics = ei[5];
   }
   I(env_ids); F(env_action_scale); F(env_ctrl_lo); F(env_ctrl_hi); F(env_reset); F(env_reward);
+  F(env_go2f); F(env_go2_scales); F(env_go2_home); F(env_go2_soft); I(env_go2i);
   return m;
 }
 #undef F
@@ -221,6 +226,8 @@ typedef struct {
   real xpos[NBODY_MAX * 3], xquat[NBODY_MAX * 4], xmat[NBODY_MAX * 9], xipos[NBODY_MAX * 3], ximat[NBODY_MAX * 9];
   real xanchor[NJNT_MAX * 3], xaxis[NJNT_MAX * 3];
   real geom_xpos[NGEOM_MAX * 3], geom_xmat[NGEOM_MAX * 9], site_xpos[NSITE_MAX * 3];
+  real site_xmat[NSITE_MAX * 9], site_linvel[NSITE_MAX * 3], site_angvel[NSITE_MAX * 3];   /* sensor sources (Go2) */
+  real actuator_force[NU_MAX];
   real subtree_com[NBODY_MAX * 3], cinert[NBODY_MAX * 10], crb[NBODY_MAX * 10], cdof[NV_MAX * 6];
   real M[NV_MAX * NV_MAX], L[NV_MAX * NV_MAX];
   /* velocity stage */
@@ -319,6 +326,9 @@ static void kinematics(const omodel *m, odata *d) {
     real sp[3] = {m->site_pos[3 * s], m->site_pos[3 * s + 1], m->site_pos[3 * s + 2]}, t[3];
     mat_mulv(t, &d->xmat[9 * b], sp);
     for (int c = 0; c < 3; c++) d->site_xpos[3 * s + c] = d->xpos[3 * b + c] + t[c];
+    real sq[4] = {m->site_quat[4 * s], m->site_quat[4 * s + 1], m->site_quat[4 * s + 2], m->site_quat[4 * s + 3]}, q[4];
+    quat_mul(q, &d->xquat[4 * b], sq);
+    quat_to_mat(&d->site_xmat[9 * s], q);
   }
 }
 
@@ -932,6 +942,15 @@ static void fwd_velocity_actuation(const omodel *m, odata *d) {
     }
     for (int c = 0; c < 6; c++) d->cvel[6 * b + c] = cvel[c];
   }
+  /* object velocities at the sites (MuJoCo mj_objectVelocity, world frame): the sources of gyro / velocimeter /
+   * framelinvel / frameangvel sensors (reference go2_mjx_feetonly.xml:207-230) */
+  for (int s_ = 0; s_ < m->nsite; s_++) {
+    int b = m->site_bodyid[s_];
+    const real *cv = &d->cvel[6 * b], *rc = &d->subtree_com[3 * m->body_rootid[b]];
+    real off[3] = {d->site_xpos[3 * s_] - rc[0], d->site_xpos[3 * s_ + 1] - rc[1], d->site_xpos[3 * s_ + 2] - rc[2]}, t[3];
+    v3cross(t, cv, off);
+    for (int c = 0; c < 3; c++) { d->site_angvel[3 * s_ + c] = cv[c]; d->site_linvel[3 * s_ + c] = cv[3 + c] + t[c]; }
+  }
   /* passive */
   for (int i = 0; i < nv; i++) d->qfrc_passive[i] = -d->dof_damping[i] * d->qvel[i];
   /* rne */
@@ -972,6 +991,7 @@ static void fwd_velocity_actuation(const omodel *m, odata *d) {
     real force = (real)m->actuator_gainprm[3 * u] * ctrl + (real)m->actuator_biasprm[3 * u] +
                  (real)m->actuator_biasprm[3 * u + 1] * length + (real)m->actuator_biasprm[3 * u + 2] * velocity;
     if (m->actuator_forcelimited[u]) force = clampr(force, m->actuator_forcerange[2 * u], m->actuator_forcerange[2 * u + 1]);
+    d->actuator_force[u] = force;
     d->qfrc_actuator[da] += gear * force;
   }
   for (int i = 0; i < nv; i++) {
@@ -1291,6 +1311,7 @@ typedef struct {
   float *info_steps, *info_truncation, *info_episode_done, *info_episode_metrics; /* wrapper info */
   /* T-shape env info (T_shape_env.py:127-134); NULL for the cube envs */
   float *info_target_base_pos, *info_target_vertical_pos, *info_target_w, *info_new_T_pos, *info_T_pos, *info_xita;
+  float *info_go2;   /* Go2 joystick info block, GO2_INFO floats per env (layout: enum G2_*); NULL otherwise */
   float *first_qpos, *first_qvel, *first_ctrl, *first_warmstart, *first_time, *first_xpos, *first_site_xpos, *first_obs;
   float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;  /* NULL = model values */
   int *stats;   /* [n][4]: solver iterations, line-search iterations, ncon, overflow (last substep) */
@@ -1671,9 +1692,306 @@ static void tshape_step_env(const omodel *m, obatch *s, int e, const float *acti
   wrappers_post(m, s, e, reward);
 }
 
+/* ================================================================== Go2 joystick env (go2/joystick.py) */
+/* info_go2 layout (floats; integers are stored as exact floats, the PRNG key as raw bits) */
+enum { G2_CMD = 0, G2_STEPS_CMD = 3, G2_LAST_ACT = 4, G2_LAST_LAST_ACT = 16, G2_AIR = 28, G2_CONTACT_T = 32, G2_LAST_CONTACT = 36,
+       G2_SWING = 40, G2_ACT_BUF = 44, G2_GYRO_BUF = 92, G2_LINVEL_BUF = 104, G2_GRAV_BUF = 116, G2_STEPS_PERT = 128,
+       G2_PERT_DUR_S = 129, G2_PERT_DUR = 130, G2_SINCE_PERT = 131, G2_PERT_STEPS = 132, G2_PERT_DIR = 133, G2_PERT_MAG = 136,
+       G2_RNG = 137 };
+/* env_go2f: 0 ctrl_dt, 1 action_scale, 2 noise level, 3 n_joint_pos, 4 n_joint_vel, 5 n_gyro, 6 n_gravity, 7 n_linvel,
+ *           8 tracking_sigma, 9 max_foot_height, 10..12 cmd_a, 13..15 cmd_b, 16 change_interval, 17..18 kick_wait,
+ *           19..20 kick_durations, 21..22 velocity_kick
+ * env_go2i: 0 action delay steps, 1 imu delay steps, 2 pert enable
+ * env_ids : 0 imu site, 1..4 feet sites (FR FL RR RL), 5 floor geom, 6..9 feet geoms, 10 torso body
+ * env_go2_scales: reward scales in reward_config order (= metrics order); env_go2_home: keyframe "home" qpos;
+ * env_go2_soft: soft lower (12) then upper (12) joint limits */
+enum { RW_TRACK_LIN = 0, RW_TRACK_ANG, RW_LIN_VEL_Z, RW_ANG_VEL_XY, RW_ORIENT, RW_DOF_LIMITS, RW_POSE, RW_TERM, RW_STAND_STILL,
+       RW_TORQUES, RW_ACTION_RATE, RW_ENERGY, RW_FEET_CLEAR, RW_FEET_HEIGHT, RW_FEET_SLIP, RW_FEET_AIR, RW_ALL_FEET_AIR,
+       RW_SYM_GAIT, RW_LR_SYM, RW_FB_SYM, RW_FEET_OFF_STILL, RW_COUNT };
+
+static inline void g2_get_key(const float *info, uint32_t key[2]) { memcpy(key, &info[G2_RNG], 8); }
+static inline void g2_set_key(float *info, const uint32_t key[2]) { memcpy(&info[G2_RNG], key, 8); }
+static float g2_uniform1(const uint32_t key[2], float lo, float hi) { float v; oracle_uniform(key, 1, &lo, &hi, 0, &v); return v; }
+
+typedef struct { float gyro[3], local_linvel[3], gravity[3], upvector[3], global_linvel[3], global_angvel[3], feet_vel[4][3],
+                 feet_z[4], act_force[NU_MAX]; int contact[4]; } g2_sensors;
+
+static void g2_read_sensors(const omodel *m, const odata *d, g2_sensors *o) {
+  const int imu = m->env_ids[0];
+  const real *R = &d->site_xmat[9 * imu];
+  real t[3], g[3] = {0, 0, -1};
+  mat_tmulv(t, R, &d->site_angvel[3 * imu]); for (int c = 0; c < 3; c++) o->gyro[c] = (float)t[c];
+  mat_tmulv(t, R, &d->site_linvel[3 * imu]); for (int c = 0; c < 3; c++) o->local_linvel[c] = (float)t[c];
+  mat_tmulv(t, R, g); for (int c = 0; c < 3; c++) o->gravity[c] = (float)t[c];
+  for (int c = 0; c < 3; c++) {
+    o->upvector[c] = (float)R[3 * c + 2];
+    o->global_linvel[c] = (float)d->site_linvel[3 * imu + c];
+    o->global_angvel[c] = (float)d->site_angvel[3 * imu + c];
+  }
+  for (int f = 0; f < 4; f++) {
+    int sid = m->env_ids[1 + f];
+    for (int c = 0; c < 3; c++) o->feet_vel[f][c] = (float)d->site_linvel[3 * sid + c];
+    o->feet_z[f] = (float)d->site_xpos[3 * sid + 2];
+    o->contact[f] = 0;
+  }
+  for (int u = 0; u < m->nu; u++) o->act_force[u] = (float)d->actuator_force[u];
+  /* collision.geoms_colliding(data, foot, floor): a contact of that pair with dist < 0 (_src/collision.py:6-18) */
+  for (int i = 0; i < d->ncon; i++) {
+    if (!(d->con[i].dist < 0)) continue;
+    int g1 = m->pair_geom1[d->con[i].pair], g2 = m->pair_geom2[d->con[i].pair];
+    for (int f = 0; f < 4; f++)
+      if ((g1 == m->env_ids[5] && g2 == m->env_ids[6 + f]) || (g2 == m->env_ids[5] && g1 == m->env_ids[6 + f])) o->contact[f] = 1;
+  }
+}
+
+/* joystick.py:284-340: the 48-dim "state" observation; advances info.rng by five splits */
+static void g2_obs(const omodel *m, float *info, const float *qpos, const float *qvel, const g2_sensors *sn, float *obs) {
+  const float *F = m->env_go2f;
+  const int imu_delay = m->env_go2i[1];
+  const float *gyro = imu_delay ? &info[G2_GYRO_BUF] : sn->gyro;
+  const float *linvel = imu_delay ? &info[G2_LINVEL_BUF] : sn->local_linvel;
+  const float *gravity = imu_delay ? &info[G2_GRAV_BUF] : sn->gravity;
+  uint32_t rng[2], ks[2][2];
+  g2_get_key(info, rng);
+  float zero = 0.0f, one = 1.0f, u[12];
+  float ngyro[3], ngrav[3], nlin[3], nq[12], nv[12];
+#define NOISE(dst, src, n, scale) do { \
+    oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1]; \
+    oracle_uniform(ks[1], n, &zero, &one, 0, u); \
+    for (int i_ = 0; i_ < n; i_++) { volatile float a_ = 2.0f * u[i_]; volatile float b_ = a_ - 1.0f; volatile float c_ = b_ * F[2]; \
+      volatile float e_ = c_ * (scale); dst[i_] = (src)[i_] + e_; } } while (0)
+  NOISE(ngyro, gyro, 3, F[5]);
+  NOISE(ngrav, gravity, 3, F[6]);
+  NOISE(nlin, linvel, 3, F[7]);
+  NOISE(nq, qpos + 7, 12, F[3]);
+  NOISE(nv, qvel + 6, 12, F[4]);
+#undef NOISE
+  g2_set_key(info, rng);
+  for (int i = 0; i < 3; i++) { obs[i] = nlin[i]; obs[3 + i] = ngyro[i]; obs[6 + i] = ngrav[i]; obs[45 + i] = info[G2_CMD + i]; }
+  for (int i = 0; i < 12; i++) { obs[9 + i] = nq[i] - m->env_go2_home[7 + i]; obs[21 + i] = nv[i]; obs[33 + i] = info[G2_LAST_ACT + i]; }
+}
+
+/* joystick.py:123-203 */
+static void go2_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], odata *d) {
+  const float *F = m->env_go2f;
+  float *info = &s->info_go2[(size_t)e * GO2_INFO];
+  memset(info, 0, sizeof(float) * GO2_INFO);
+  uint32_t rng[2] = {key[0], key[1]}, ks[4][2];
+  float qpos[NQ_MAX], qvel[NV_MAX];
+  for (int i = 0; i < m->nq; i++) qpos[i] = m->env_go2_home[i];
+  for (int i = 0; i < m->nv; i++) qvel[i] = 0;
+  float lo = -0.5f, hi = 0.5f, u[8];
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  oracle_uniform(ks[1], 2, &lo, &hi, 0, u);
+  qpos[0] += u[0]; qpos[1] += u[1];
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  float yaw = g2_uniform1(ks[1], -3.14f, 3.14f);
+  {
+    float sn = sinf(yaw * 0.5f), cs = cosf(yaw * 0.5f);
+    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]}, r[4] = {cs, 0.0f * sn, 0.0f * sn, 1.0f * sn};
+    qpos[3] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+    qpos[4] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+    qpos[5] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+    qpos[6] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+  }
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  oracle_uniform(ks[1], 6, &lo, &hi, 0, u);
+  for (int i = 0; i < 6; i++) qvel[i] = u[i];
+  /* mjx_env.init(qpos, qvel, ctrl = qpos[7:]) = make_data + forward (_src/mjx_env.py:30-54) */
+  s->time[e] = 0;
+  for (int i = 0; i < m->nq; i++) s->qpos[e * m->nq + i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) { s->qvel[e * m->nv + i] = qvel[i]; s->qacc_warmstart[e * m->nv + i] = 0; }
+  for (int i = 0; i < m->nu; i++) s->ctrl[e * m->nu + i] = qpos[7 + i];
+  load_env(m, s, e, d);
+  forward(m, d);
+  store_pipeline(m, s, e, d);
+  oracle_split(rng, 4, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  float t_pert = g2_uniform1(ks[1], F[17], F[18]);
+  info[G2_STEPS_PERT] = rintf(t_pert / F[0]);
+  info[G2_PERT_DUR_S] = g2_uniform1(ks[2], F[19], F[20]);
+  info[G2_PERT_DUR] = rintf(info[G2_PERT_DUR_S] / F[0]);
+  info[G2_PERT_MAG] = g2_uniform1(ks[3], F[21], F[22]);
+  oracle_split(rng, 3, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  {
+    float uu = g2_uniform1(ks[1], 0.0f, 1.0f);
+    float t_cmd = -log1pf(-uu) * F[16];
+    info[G2_STEPS_CMD] = rintf(t_cmd / F[0]);
+    float a_lo[3] = {-F[10], -F[11], -F[12]}, a_hi[3] = {F[10], F[11], F[12]};
+    oracle_uniform(ks[2], 3, a_lo, a_hi, 1, &info[G2_CMD]);
+  }
+  g2_set_key(info, rng);
+  for (int i = 0; i < m->nmetrics; i++) s->metrics[e * m->nmetrics + i] = 0;
+  g2_sensors sn;
+  g2_read_sensors(m, d, &sn);
+  g2_obs(m, info, &s->qpos[e * m->nq], &s->qvel[e * m->nv], &sn, &s->obs[e * m->obs_dim]);
+  s->reward[e] = 0; s->done[e] = 0;
+  wrappers_reset(m, s, e);
+}
+
+static float g2_norm3(const float *v) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+/* joystick.py:204-280 with rewards :367-593 and sample_command :645-653 */
+static void go2_step_env(const omodel *m, obatch *s, int e, const float *action, odata *d) {
+  const float *F = m->env_go2f, *SC = m->env_go2_scales, *home = m->env_go2_home;
+  const int nu = m->nu;
+  const float dt = F[0];
+  float *info = &s->info_go2[(size_t)e * GO2_INFO];
+  const float *act_in = &action[e * nu];
+  if ((m->wrap_flags & 2) != 0) { if (s->done[e] != 0) s->info_steps[e] = 0; s->done[e] = 0; }
+  /* action delay FIFO (:207-215) */
+  float actual[NU_MAX];
+  const int adel = m->env_go2i[0];
+  if (adel > 0) {
+    for (int i = 0; i < nu; i++) actual[i] = info[G2_ACT_BUF + i];
+    memmove(&info[G2_ACT_BUF], &info[G2_ACT_BUF + nu], sizeof(float) * (size_t)adel * nu);
+    for (int i = 0; i < nu; i++) info[G2_ACT_BUF + adel * nu + i] = act_in[i];
+  } else for (int i = 0; i < nu; i++) actual[i] = act_in[i];
+  load_env(m, s, e, d);
+  for (int i = 0; i < nu; i++) { volatile float sc = actual[i] * F[1]; d->ctrl[i] = home[7 + i] + sc; }
+  for (int f = 0; f < m->n_frames; f++) step_physics(m, d);
+  store_pipeline(m, s, e, d);
+  const float *qpos = &s->qpos[e * m->nq], *qvel = &s->qvel[e * m->nv];
+  g2_sensors sn;
+  g2_read_sensors(m, d, &sn);
+  /* IMU delay FIFOs (:220-235) */
+  const int idel = m->env_go2i[1];
+  if (idel > 0) {
+    float *bufs[3] = {&info[G2_GYRO_BUF], &info[G2_LINVEL_BUF], &info[G2_GRAV_BUF]};
+    const float *cur[3] = {sn.gyro, sn.local_linvel, sn.gravity};
+    for (int b = 0; b < 3; b++) {
+      memmove(bufs[b], bufs[b] + 3, sizeof(float) * (size_t)idel * 3);
+      for (int c = 0; c < 3; c++) bufs[b][idel * 3 + c] = cur[b][c];
+    }
+  }
+  int contact[4], contact_filt[4], first_contact[4];
+  for (int f = 0; f < 4; f++) {
+    contact[f] = sn.contact[f];
+    contact_filt[f] = contact[f] || info[G2_LAST_CONTACT + f] != 0;
+    first_contact[f] = (info[G2_AIR + f] > 0.0f) && contact_filt[f];
+    info[G2_AIR + f] += dt;
+    if (sn.feet_z[f] > info[G2_SWING + f]) info[G2_SWING + f] = sn.feet_z[f];
+  }
+  g2_obs(m, info, qpos, qvel, &sn, &s->obs[e * m->obs_dim]);
+  float done = sn.upvector[2] < 0.0f ? 1.0f : 0.0f;
+  /* ---- reward terms ---- */
+  const float *cmd = &info[G2_CMD];
+  float cmd_norm = g2_norm3(cmd);
+  float moving = cmd_norm > 0.01f ? 1.0f : 0.0f, still = cmd_norm < 0.01f ? 1.0f : 0.0f;
+  float rw[RW_COUNT];
+  {
+    float e0 = cmd[0] - sn.local_linvel[0], e1 = cmd[1] - sn.local_linvel[1];
+    rw[RW_TRACK_LIN] = expf(-(e0 * e0 + e1 * e1) / F[8]);
+    float ea = cmd[2] - sn.gyro[2];
+    rw[RW_TRACK_ANG] = expf(-(ea * ea) / F[8]);
+  }
+  rw[RW_LIN_VEL_Z] = sn.global_linvel[2] * sn.global_linvel[2];
+  rw[RW_ANG_VEL_XY] = sn.global_angvel[0] * sn.global_angvel[0] + sn.global_angvel[1] * sn.global_angvel[1];
+  rw[RW_ORIENT] = sn.upvector[0] * sn.upvector[0] + sn.upvector[1] * sn.upvector[1];
+  {
+    float sa = 0, lim = 0, pose = 0;
+    for (int i = 0; i < 12; i++) {
+      float q = qpos[7 + i], dq = q - home[7 + i];
+      sa += fabsf(dq);
+      float lo_ = q - m->env_go2_soft[i], hi_ = q - m->env_go2_soft[12 + i];
+      lim += -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
+      float w = (i % 3 == 2) ? 0.1f : 1.0f;
+      pose += dq * dq * w;
+    }
+    rw[RW_STAND_STILL] = sa * still;
+    rw[RW_DOF_LIMITS] = lim;
+    rw[RW_POSE] = expf(-pose);
+  }
+  rw[RW_TERM] = done;
+  {
+    float s2 = 0, s1 = 0, en = 0;
+    for (int i = 0; i < 12; i++) { float t = sn.act_force[i]; s2 += t * t; s1 += fabsf(t); en += fabsf(qvel[6 + i]) * fabsf(t); }
+    rw[RW_TORQUES] = sqrtf(s2) + s1;
+    rw[RW_ENERGY] = en;
+    float ar = 0;
+    for (int i = 0; i < 12; i++) { float dd = act_in[i] - info[G2_LAST_ACT + i]; ar += dd * dd; }
+    rw[RW_ACTION_RATE] = ar;
+  }
+  {
+    float slip = 0, clear = 0, height = 0, air = 0; int nair = 0;
+    for (int f = 0; f < 4; f++) {
+      float vx = sn.feet_vel[f][0], vy = sn.feet_vel[f][1];
+      float v2 = vx * vx + vy * vy;
+      slip += v2 * (float)contact[f];
+      clear += fabsf(sn.feet_z[f] - F[9]) * sqrtf(sqrtf(v2));
+      float err = info[G2_SWING + f] / F[9] - 1.0f;
+      height += err * err * (float)first_contact[f];
+      air += (info[G2_AIR + f] - 0.1f) * (float)first_contact[f];
+      nair += !contact[f];
+    }
+    rw[RW_FEET_SLIP] = slip * moving;
+    rw[RW_FEET_CLEAR] = clear;
+    rw[RW_FEET_HEIGHT] = height * moving;
+    rw[RW_FEET_AIR] = air * moving;
+    rw[RW_ALL_FEET_AIR] = (nair >= 3 ? 1.0f : 0.0f) * moving;
+    rw[RW_FEET_OFF_STILL] = (float)nair * still;
+    float p1 = 0, p2 = 0;
+    for (int i = 0; i < 3; i++) { float a = qpos[7 + 3 + i] - qpos[7 + 6 + i], b = qpos[7 + i] - qpos[7 + 9 + i]; p1 += a * a; p2 += b * b; }
+    rw[RW_SYM_GAIT] = (p1 + p2) * moving;
+    const float *at = &info[G2_AIR], *ct = &info[G2_CONTACT_T];
+    float la = (at[1] + at[3]) / 2.0f, lc = (ct[1] + ct[3]) / 2.0f, ra = (at[0] + at[2]) / 2.0f, rc = (ct[0] + ct[2]) / 2.0f;
+    rw[RW_LR_SYM] = ((la - ra) * (la - ra) + (lc - rc) * (lc - rc)) * moving;
+    float fa = (at[0] + at[1]) / 2.0f, fc = (ct[0] + ct[1]) / 2.0f, ba = (at[2] + at[3]) / 2.0f, bc = (ct[2] + ct[3]) / 2.0f;
+    rw[RW_FB_SYM] = ((fa - ba) * (fa - ba) + (fc - bc) * (fc - bc)) * moving;
+  }
+  for (int k = 0; k < RW_COUNT; k++) { volatile float v = rw[k] * SC[k]; rw[k] = v; }
+  /* sum(rewards.values()) in the insertion order of _get_reward's dict (:378-423) */
+  static const int order[RW_COUNT] = {RW_TRACK_LIN, RW_TRACK_ANG, RW_LIN_VEL_Z, RW_ANG_VEL_XY, RW_ORIENT, RW_STAND_STILL, RW_TERM, RW_POSE,
+                                      RW_TORQUES, RW_ACTION_RATE, RW_ENERGY, RW_FEET_SLIP, RW_FEET_CLEAR, RW_FEET_HEIGHT, RW_FEET_AIR,
+                                      RW_DOF_LIMITS, RW_ALL_FEET_AIR, RW_SYM_GAIT, RW_LR_SYM, RW_FB_SYM, RW_FEET_OFF_STILL};
+  volatile float total = 0.0f;
+  for (int k = 0; k < RW_COUNT; k++) total = total + rw[order[k]];
+  float reward = total * dt;
+  reward = reward < 0.0f ? 0.0f : (reward > 10000.0f ? 10000.0f : reward);
+  /* ---- bookkeeping (:255-277) ---- */
+  for (int i = 0; i < 12; i++) { info[G2_LAST_LAST_ACT + i] = info[G2_LAST_ACT + i]; info[G2_LAST_ACT + i] = act_in[i]; }
+  info[G2_STEPS_CMD] -= 1.0f;
+  uint32_t rng[2], ks[4][2];
+  g2_get_key(info, rng);
+  oracle_split(rng, 3, &ks[0][0]);
+  g2_set_key(info, ks[0]);
+  {   /* sample_command(key1, command) */
+    uint32_t k4[4][2];
+    oracle_split(ks[1], 4, &k4[0][0]);          /* rng, y_rng, w_rng, z_rng */
+    float a_lo[3] = {-F[10], -F[11], -F[12]}, a_hi[3] = {F[10], F[11], F[12]}, y[3], uz[3], uw[3], zero = 0.0f, one = 1.0f;
+    oracle_uniform(k4[1], 3, a_lo, a_hi, 1, y);
+    oracle_uniform(k4[3], 3, &zero, &one, 0, uz);
+    oracle_uniform(k4[2], 3, &zero, &one, 0, uw);
+    if (info[G2_STEPS_CMD] <= 0.0f)
+      for (int i = 0; i < 3; i++) {
+        float z = uz[i] < F[13 + i] ? 1.0f : 0.0f, w = uw[i] < 0.5f ? 1.0f : 0.0f;
+        volatile float yz = y[i] * z; volatile float dif = info[G2_CMD + i] - yz; volatile float wd = w * dif;
+        info[G2_CMD + i] = info[G2_CMD + i] - wd;
+      }
+  }
+  if (done != 0.0f || info[G2_STEPS_CMD] <= 0.0f) {
+    float uu = g2_uniform1(ks[2], 0.0f, 1.0f);
+    volatile float t1 = -log1pf(-uu) * F[16];
+    info[G2_STEPS_CMD] = rintf(t1 / dt);
+  }
+  float swing_mean = 0;
+  for (int f = 0; f < 4; f++) {
+    float c = (float)contact[f], nc = 1.0f - c;
+    info[G2_AIR + f] = (info[G2_AIR + f] + dt) * nc;
+    info[G2_CONTACT_T + f] = (info[G2_CONTACT_T + f] + dt) * c;
+    info[G2_LAST_CONTACT + f] = c;
+    info[G2_SWING + f] *= nc;
+    swing_mean += info[G2_SWING + f];
+  }
+  float *met = &s->metrics[e * m->nmetrics];
+  for (int k = 0; k < RW_COUNT; k++) met[k] = rw[k];
+  met[RW_COUNT] = swing_mean / 4.0f;
+  s->reward[e] = reward; s->done[e] = done;
+  wrappers_post(m, s, e, reward);
+}
+
 /* ------------------------------------------------------------------ exported batch entry points */
 int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -1684,7 +2002,9 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
 #pragma omp for schedule(dynamic, 8)
 #endif
     for (int e = 0; e < s->n; e++) {
-      if (m->env_kind == ENV_TSHAPE) tshape_reset_env(m, s, e, &keys[2 * e], d); else reset_env(m, s, e, &keys[2 * e], d);
+      if (m->env_kind == ENV_TSHAPE) tshape_reset_env(m, s, e, &keys[2 * e], d);
+      else if (m->env_kind == ENV_GO2) go2_reset_env(m, s, e, &keys[2 * e], d);
+      else reset_env(m, s, e, &keys[2 * e], d);
     }
     odata_free(d);
   }
@@ -1692,7 +2012,7 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
 }
 
 int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -1703,7 +2023,9 @@ int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads
 #pragma omp for schedule(dynamic, 8)
 #endif
     for (int e = 0; e < s->n; e++) {
-      if (m->env_kind == ENV_TSHAPE) tshape_step_env(m, s, e, action, d); else step_env(m, s, e, action, d);
+      if (m->env_kind == ENV_TSHAPE) tshape_step_env(m, s, e, action, d);
+      else if (m->env_kind == ENV_GO2) go2_step_env(m, s, e, action, d);
+      else step_env(m, s, e, action, d);
     }
     odata_free(d);
   }
@@ -1742,6 +2064,8 @@ int oracle_debug_get(const omodel *m, const char *name, double *out, int cap) {
   G("qpos", d->qpos, m->nq) G("qvel", d->qvel, m->nv) G("xpos", d->xpos, 3 * m->nbody) G("xquat", d->xquat, 4 * m->nbody)
   G("xmat", d->xmat, 9 * m->nbody) G("xipos", d->xipos, 3 * m->nbody) G("ximat", d->ximat, 9 * m->nbody)
   G("geom_xpos", d->geom_xpos, 3 * m->ngeom) G("geom_xmat", d->geom_xmat, 9 * m->ngeom) G("site_xpos", d->site_xpos, 3 * m->nsite)
+  G("site_xmat", d->site_xmat, 9 * m->nsite) G("site_linvel", d->site_linvel, 3 * m->nsite) G("site_angvel", d->site_angvel, 3 * m->nsite)
+  G("actuator_force", d->actuator_force, m->nu)
   G("subtree_com", d->subtree_com, 3 * m->nbody) G("cinert", d->cinert, 10 * m->nbody) G("cdof", d->cdof, 6 * m->nv)
   G("cvel", d->cvel, 6 * m->nbody) G("cdof_dot", d->cdof_dot, 6 * m->nv)
   G("M", d->M, m->nv * m->nv) G("qfrc_bias", d->qfrc_bias, m->nv) G("qfrc_passive", d->qfrc_passive, m->nv)

@@ -38,7 +38,7 @@ struct DModel {
   const int *geom_bodyid, *geom_priority;
   const float *geom_size, *geom_pos, *geom_quat, *geom_friction;
   const int *site_bodyid;
-  const float *site_pos;
+  const float *site_pos, *site_quat;
   const int *eq_obj1id, *eq_obj2id, *eq_active0;
   const float *eq_data, *eq_solref, *eq_solimp;
   const int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
@@ -78,17 +78,19 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4>
 struct Dims {
+  static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
   static constexpr int LD = NV_ + 1;                        // padded row stride: conflict-free row and column reads
-  static constexpr int NEFC = NEQ_ + NF_ + NL_ + 6 * NCON_;   // constraint-row capacity (pyramid rows)
+  static constexpr int NPYR = 2 * (CONDIM_ - 1);             // pyramid edges per contact
+  static constexpr int NEFC = NEQ_ + NF_ + NL_ + NPYR * NCON_;   // constraint-row capacity (pyramid rows)
   static constexpr int NCHUNK = (NEFC + 63) / 64;           // rows per lane
-  // The Jacobian is stored as BASE rows: the sparse rows as they are, and per contact the four contact-frame
-  // rows (normal, tangent 1, tangent 2, torsion); the six pyramid edges are +-mu combinations of those.
-  static constexpr int NBC = 4;
+  // The Jacobian is stored as BASE rows: the sparse rows as they are, and per contact the CONDIM contact-frame
+  // rows (normal, tangent 1, tangent 2[, torsion]); the pyramid edges are +-mu combinations of those.
+  static constexpr int NBC = CONDIM_;
   static constexpr int NSP = NEQ_ + NF_ + NL_;
   static constexpr int NBASE = NSP + NBC * NCON_;
   static constexpr int NCHB = (NBASE + 63) / 64;
@@ -208,6 +210,8 @@ struct Smem {
   float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
   float xpos[C::NB * 3], xquat[C::NB * 4], spos[C::NS * 3];   // also read by the env epilogue
   float egeom[(C::NEG > 0 ? C::NEG : 1) * 3];          // world positions of the env's geoms of interest
+  float smat[C::NS * 9], slinvel[C::NS * 3], sangvel[C::NS * 3];   // site frames / object velocities (sensor sources)
+  float aforce[C::NU];                                 // actuator_force of the last forward pass
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
   float M[C::NV * C::LD], T[C::NV * C::LD];
   // contacts (active only)
@@ -218,7 +222,7 @@ struct Smem {
   float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
   float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction
-  float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian
+  float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian (2*NBC-1 used)
   int rlist[C::NBASE + 4];                             // compacted base rows / contacts with non-zero weight
   int clist[C::NCON + 4];
   union X { PhaseA<C> a; PhaseB<C> b; } x;
@@ -303,6 +307,9 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
   if (lane < C::NS) {
     int sb = m.site_bodyid[lane];
     st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.x.a.xmat[9 * sb], ld3(&m.site_pos[3 * lane])));
+    M33 Rs = q2m(qmul(ld4(&s.xquat[4 * sb]), ld4(&m.site_quat[4 * lane])));
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.smat[9 * lane + c] = Rs.m[c];
   }
   WSYNC();
 }
@@ -780,6 +787,13 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     for (int c = 0; c < 6; ++c) s.x.a.cdofdot[6 * lane + c] = free_trans ? 0.0f : o[c];
   }
   WSYNC();
+  // object velocity at every site, world frame (source of gyro / velocimeter / framelinvel / frameangvel sensors)
+  if (lane < C::NS) {
+    int sb = m.site_bodyid[lane];
+    V3 w = ld3(&s.x.a.cvel[6 * sb]), v = ld3(&s.x.a.cvel[6 * sb + 3]);
+    V3 off = ld3(&s.spos[3 * lane]) - ld3(&s.com[3 * m.body_rootid[sb]]);
+    st3(&s.sangvel[3 * lane], w); st3(&s.slinvel[3 * lane], v + cross(w, off));
+  }
   // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
@@ -826,6 +840,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
       float force = m.actuator_gainprm[3 * u] * ctrl + m.actuator_biasprm[3 * u] + m.actuator_biasprm[3 * u + 1] * length +
                     m.actuator_biasprm[3 * u + 2] * velocity;
       if (m.actuator_forcelimited[u]) force = clampf(force, m.actuator_forcerange[2 * u], m.actuator_forcerange[2 * u + 1]);
+      s.aforce[u] = force;
       act += gear * force;
     }
     int j = m.dof_jntid[i];
@@ -886,7 +901,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   if (lim_active) s.lim_jnt[__popcll(bal & ((1ull << lane) - 1ull))] = m.limit_jnts[lane];
   const int r_fric = C::NEQ, r_lim = C::NEQ + C::NF, r_con = r_lim + nl;
   const int ncon = s.ncon;
-  const int nefc = r_con + 6 * ncon;
+  const int nefc = r_con + C::NPYR * ncon;
   WSYNC();
   // zero the sparse rows, then poke their entries
   for (int t = lane; t < r_con * LD; t += 64) s.x.b.J[t] = 0.0f;
@@ -922,7 +937,8 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
     V3 jr = ang * (in2 - in1);
     float* Jr = &s.x.b.J[(r_con + C::NBC * c) * LD + i];
-    Jr[0 * LD] = dot(nn, jp); Jr[1 * LD] = dot(t1, jp); Jr[2 * LD] = dot(t2, jp); Jr[3 * LD] = dot(nn, jr);
+    Jr[0 * LD] = dot(nn, jp); Jr[1 * LD] = dot(t1, jp); Jr[2 * LD] = dot(t2, jp);
+    if constexpr (C::NBC > 3) Jr[3 * LD] = dot(nn, jr);
   }
   // friction coefficient of each contact base row (normal: unused)
   for (int t = lane; t < ncon * C::NBC; t += 64) {
@@ -960,7 +976,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
         pos = fminf(q - m.jnt_range[2 * j], m.jnt_range[2 * j + 1] - q) - m.jnt_margin[j];
         invw = m.dof_invweight0[m.jnt_dofadr[j]]; sr0 = m.jnt_solref[2 * j]; sr1 = m.jnt_solref[2 * j + 1]; si = &m.jnt_solimp[5 * j];
       } else {
-        int c = (r - r_con) / 6, e = (r - r_con) - 6 * c, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+        int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
         pos = s.cdist[c] - (m.pair_margin[p] - m.pair_gap[p]);
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];

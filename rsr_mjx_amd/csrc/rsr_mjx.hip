@@ -524,7 +524,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(unsigned, dof_ancmask) P(unsigned, dof_velmask) P(unsigned, body_dofmask) P(unsigned, body_submask)
   P(float, dof_armature) P(float, dof_damping) P(float, dof_frictionloss) P(float, dof_invweight0) P(float, dof_solref) P(float, dof_solimp)
   P(int, geom_bodyid) P(int, geom_priority) P(float, geom_size) P(float, geom_pos) P(float, geom_quat) P(float, geom_friction)
-  P(int, site_bodyid) P(float, site_pos)
+  P(int, site_bodyid) P(float, site_pos) P(float, site_quat)
   P(int, eq_obj1id) P(int, eq_obj2id) P(int, eq_active0) P(float, eq_data) P(float, eq_solref) P(float, eq_solimp)
   P(int, actuator_trnid) P(int, actuator_ctrllimited) P(int, actuator_forcelimited)
   P(float, actuator_gear) P(float, actuator_gainprm) P(float, actuator_biasprm) P(float, actuator_ctrlrange) P(float, actuator_forcerange)

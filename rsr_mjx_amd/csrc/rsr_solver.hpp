@@ -143,7 +143,7 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = force[ch]; }
   WSYNC();
-  const int rcon = nefc - 6 * s.ncon;           // first contact row (pyramid and base numbering agree below it)
+  const int rcon = nefc - C::NPYR * s.ncon;     // first contact row (pyramid and base numbering agree below it)
   bool on[C::NCHB];
 #pragma unroll
   for (int ch = 0; ch < C::NCHB; ++ch) {
@@ -151,9 +151,11 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
     float g = 0.0f;
     if (b < rcon) g = s.rw[b];
     else if (b < nbase) {
-      int c = (b - rcon) >> 2, k = (b - rcon) & 3, r0 = rcon + 6 * c;
-      if (k == 0) g = ((s.rw[r0] + s.rw[r0 + 1]) + (s.rw[r0 + 2] + s.rw[r0 + 3])) + (s.rw[r0 + 4] + s.rw[r0 + 5]);
-      else g = s.bmu[b] * (s.rw[r0 + 2 * (k - 1)] - s.rw[r0 + 2 * (k - 1) + 1]);
+      int c = (b - rcon) / C::NBC, k = (b - rcon) - C::NBC * c, r0 = rcon + C::NPYR * c;
+      if (k == 0) {
+#pragma unroll
+        for (int e = 0; e < C::NPYR; e += 2) g += s.rw[r0 + e] + s.rw[r0 + e + 1];
+      } else g = s.bmu[b] * (s.rw[r0 + 2 * (k - 1)] - s.rw[r0 + 2 * (k - 1) + 1]);
     }
     if (b < nbase) s.bval[b] = g;
     on[ch] = b < nbase && g != 0.0f;
@@ -184,19 +186,23 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = hw[ch]; }
   WSYNC();
-  const int ncon = s.ncon, rcon = nefc - 6 * ncon;
+  const int ncon = s.ncon, rcon = nefc - C::NPYR * ncon;
   bool son[1] = {lane < rcon && s.rw[lane < rcon ? lane : 0] != 0.0f};
   const int nsp = compact_list<1>(s.rlist, lane, son, C::NBASE);
   bool con[1] = {false};
   if (lane < ncon) {
-    int r0 = rcon + 6 * lane, b0 = rcon + 4 * lane;
-    float h0 = s.rw[r0], h1 = s.rw[r0 + 1], h2 = s.rw[r0 + 2], h3 = s.rw[r0 + 3], h4 = s.rw[r0 + 4], h5 = s.rw[r0 + 5];
-    float m1 = s.bmu[b0 + 1], m2 = s.bmu[b0 + 2], m3 = s.bmu[b0 + 3];
+    int r0 = rcon + C::NPYR * lane, b0 = rcon + C::NBC * lane;
     float* w = &s.wc[8 * lane];
-    w[0] = ((h0 + h1) + (h2 + h3)) + (h4 + h5);
-    w[1] = m1 * (h0 - h1); w[2] = m2 * (h2 - h3); w[3] = m3 * (h4 - h5);
-    w[4] = m1 * m1 * (h0 + h1); w[5] = m2 * m2 * (h2 + h3); w[6] = m3 * m3 * (h4 + h5);
-    con[0] = w[0] != 0.0f;
+    float wnn = 0.0f;
+#pragma unroll
+    for (int k = 1; k < C::NBC; ++k) {
+      float hp = s.rw[r0 + 2 * (k - 1)], hm = s.rw[r0 + 2 * (k - 1) + 1], mu = s.bmu[b0 + k];
+      wnn += hp + hm;
+      w[k] = mu * (hp - hm);
+      w[C::NBC - 1 + k] = mu * mu * (hp + hm);
+    }
+    w[0] = wnn;
+    con[0] = wnn != 0.0f;
   }
   const int nc = compact_list<1>(s.clist, lane, con, -1);
   WSYNC();
@@ -219,22 +225,20 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
   }
   for (int k = 0; k < nc; ++k) {
     int c = s.clist[k];
-    const float* B = &s.x.b.J[(rcon + 4 * c) * C::LD];
+    const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LD];
     const float* w = &s.wc[8 * c];
-    float wnn = w[0], wn1 = w[1], wn2 = w[2], wn3 = w[3], w11 = w[4], w22 = w[5], w33 = w[6];
     float ni0 = B[i0], ni1 = B[i0 + 1], nj0 = B[j0], nj1 = B[j0 + 1];
-    float pi0 = B[C::LD + i0], pi1 = B[C::LD + i0 + 1], pj0 = B[C::LD + j0], pj1 = B[C::LD + j0 + 1];
-    float qi0 = B[2 * C::LD + i0], qi1 = B[2 * C::LD + i0 + 1], qj0 = B[2 * C::LD + j0], qj1 = B[2 * C::LD + j0 + 1];
-    float ti0 = B[3 * C::LD + i0], ti1 = B[3 * C::LD + i0 + 1], tj0 = B[3 * C::LD + j0], tj1 = B[3 * C::LD + j0 + 1];
-    // (W b_j) for the two columns of the block
-    float u0n = wnn * nj0 + wn1 * pj0 + wn2 * qj0 + wn3 * tj0, u1n = wnn * nj1 + wn1 * pj1 + wn2 * qj1 + wn3 * tj1;
-    float u0p = wn1 * nj0 + w11 * pj0, u1p = wn1 * nj1 + w11 * pj1;
-    float u0q = wn2 * nj0 + w22 * qj0, u1q = wn2 * nj1 + w22 * qj1;
-    float u0t = wn3 * nj0 + w33 * tj0, u1t = wn3 * nj1 + w33 * tj1;
-    h00 += ni0 * u0n + pi0 * u0p + qi0 * u0q + ti0 * u0t;
-    h01 += ni0 * u1n + pi0 * u1p + qi0 * u1q + ti0 * u1t;
-    h10 += ni1 * u0n + pi1 * u0p + qi1 * u0q + ti1 * u0t;
-    h11 += ni1 * u1n + pi1 * u1p + qi1 * u1q + ti1 * u1t;
+    float u0n = w[0] * nj0, u1n = w[0] * nj1;          // (W b_j)[normal] for the two columns of the block
+    float a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll
+    for (int d = 1; d < C::NBC; ++d) {
+      float wn = w[d], wd = w[C::NBC - 1 + d];
+      float di0 = B[d * C::LD + i0], di1 = B[d * C::LD + i0 + 1], dj0 = B[d * C::LD + j0], dj1 = B[d * C::LD + j0 + 1];
+      u0n += wn * dj0; u1n += wn * dj1;
+      float u0d = wn * nj0 + wd * dj0, u1d = wn * nj1 + wd * dj1;   // (W b_j)[direction d]
+      a00 += di0 * u0d; a01 += di0 * u1d; a10 += di1 * u0d; a11 += di1 * u1d;
+    }
+    h00 += ni0 * u0n + a00; h01 += ni0 * u1n + a01; h10 += ni1 * u0n + a10; h11 += ni1 * u1n + a11;
   }
   if (blk) {
     s.T[i0 * C::LD + j0] = h00; s.T[(i0 + 1) * C::LD + j0] = h10; s.T[(i0 + 1) * C::LD + j0 + 1] = h11;
@@ -430,13 +434,13 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
       if (r < nefc && r < 256) { dbg[1152 + r] = rr[ch].aref; dbg[1408 + r] = rr[ch].D; }
     }
     {
-      const int rcon = nefc - 6 * s.ncon;
+      const int rcon = nefc - C::NPYR * s.ncon;
       for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) {
         int r = t / C::NV, i = t % C::NV;
         float v;
         if (r < rcon) v = s.x.b.J[r * C::LD + i];
         else {
-          int c = (r - rcon) / 6, e = (r - rcon) % 6, bn = rcon + 4 * c, bk = bn + 1 + (e >> 1);
+          int c = (r - rcon) / C::NPYR, e = (r - rcon) % C::NPYR, bn = rcon + C::NBC * c, bk = bn + 1 + (e >> 1);
           v = s.x.b.J[bn * C::LD + i] + ((e & 1) ? -s.bmu[bk] : s.bmu[bk]) * s.x.b.J[bk * C::LD + i];
         }
         dbg[2048 + t] = v;

@@ -118,3 +118,83 @@ def tshape_env_fields(m: CompiledModel, episode_length: int = 0, auto_reset: boo
         env_reset=reset,
         env_reward=reward,
     )
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Go2 joystick task: reference mujoco_playground/_src/locomotion/go2/joystick.py:13-82 (default_config)
+GO2_OBS_DIM = 48
+GO2_REWARDS = ("tracking_lin_vel", "tracking_ang_vel", "lin_vel_z", "ang_vel_xy", "orientation", "dof_pos_limits", "pose",
+               "termination", "stand_still", "torques", "action_rate", "energy", "feet_clearance", "feet_height", "feet_slip",
+               "feet_air_time", "all_feet_air", "symmetric_gait", "lr_symmetry", "fb_symmetry", "feet_off_ground_when_still")
+GO2_METRICS = tuple(f"reward/{k}" for k in GO2_REWARDS) + ("swing_peak",)
+GO2_INFO_FLOATS = 144
+GO2_DEFAULT_CONFIG = dict(
+    ctrl_dt=0.02, sim_dt=0.004, episode_length=1000, Kp=60.0, Kd=3.0, action_repeat=1, action_scale=0.5, history_len=1,
+    soft_joint_pos_limit_factor=0.95,
+    noise_config=dict(level=1.0, scales=dict(joint_pos=0.03, joint_vel=1.5, gyro=0.2, gravity=0.05, linvel=0.1)),
+    reward_config=dict(
+        scales=dict(tracking_lin_vel=3.0, tracking_ang_vel=1.5, lin_vel_z=-0.5, ang_vel_xy=-0.05, orientation=-3.0,
+                    dof_pos_limits=-1.0, pose=0.0, termination=-1.0, stand_still=-1.0, torques=-0.0002, action_rate=-0.01,
+                    energy=-0.001, feet_clearance=-2.0, feet_height=-3.5, feet_slip=-0.1, feet_air_time=0.8,
+                    all_feet_air=-1.0, symmetric_gait=-0.8, lr_symmetry=-0.8, fb_symmetry=-0.8,
+                    feet_off_ground_when_still=-1.0),
+        tracking_sigma=0.25, max_foot_height=0.12),
+    pert_config=dict(enable=False, velocity_kick=[0.0, 3.0], kick_durations=[0.05, 0.2], kick_wait_times=[1.0, 3.0]),
+    command_config=dict(a=[0.8, 0.0, 2.0], b=[0.8, 0.0, 0.8], change_interval=12.0),
+    delay_config=dict(action=dict(enable=True, steps=3), imu=dict(enable=True, steps=3)),
+)
+
+
+def _merge(base: dict, over: dict) -> dict:
+    out = {k: (dict(v) if isinstance(v, dict) else v) for k, v in base.items()}
+    for k, v in (over or {}).items():
+        if k not in out:
+            raise KeyError(f"unknown Go2 config key {k!r}")     # the reference ConfigDict is locked (_src/mjx_env.py:104-106)
+        out[k] = _merge(out[k], v) if isinstance(v, dict) and isinstance(out[k], dict) else v
+    return out
+
+
+def go2_apply_overrides(m: CompiledModel, config: dict) -> CompiledModel:
+    """go2/base.py:25-31: timestep, dof_damping[6:] = Kd, position servos gain/bias = +-Kp."""
+    A = {k: v.copy() for k, v in m.arrays.items()}
+    A["opt_timestep"][0] = config["sim_dt"]
+    A["dof_damping"][6:] = config["Kd"]
+    A["actuator_gainprm"][:, 0] = config["Kp"]
+    A["actuator_biasprm"][:, 1] = -config["Kp"]
+    return CompiledModel(name=m.name, arrays=A, names=m.names)
+
+
+def go2_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto_reset: bool = False) -> Dict[str, np.ndarray]:
+    """`m` must already carry the base.py overrides (go2_apply_overrides)."""
+    if config["pert_config"]["enable"]:
+        raise NotImplementedError("perturbation kicks (joystick.py:594-644) are not built; the reference default disables them")
+    if config["action_repeat"] != 1:
+        raise NotImplementedError("action_repeat != 1")
+    A = m.arrays
+    n_sub = int(round(config["ctrl_dt"] / config["sim_dt"]))      # _src/mjx_env.py:139-142
+    home = A["key_qpos"][m.names["key"]["home"]].astype(np.float32)
+    lo, hi = A["jnt_range"][1:, 0], A["jnt_range"][1:, 1]
+    soft = np.concatenate([lo, hi]).astype(np.float32) * np.float32(config["soft_joint_pos_limit_factor"])
+    feet = ["FR", "FL", "RR", "RL"]                                # go2_constants.py:20-31
+    ids = np.array([m.id("site", "imu")] + [m.id("site", f) for f in feet] + [m.id("geom", "floor")] +
+                   [m.id("geom", f) for f in feet] + [m.id("body", "trunk")], dtype=np.int32)
+    nz, rc, cc, pc, dc = (config[k] for k in ("noise_config", "reward_config", "command_config", "pert_config", "delay_config"))
+    f = np.array([config["ctrl_dt"], config["action_scale"], nz["level"], nz["scales"]["joint_pos"], nz["scales"]["joint_vel"],
+                  nz["scales"]["gyro"], nz["scales"]["gravity"], nz["scales"]["linvel"], rc["tracking_sigma"], rc["max_foot_height"],
+                  *cc["a"], *cc["b"], cc["change_interval"], *pc["kick_wait_times"], *pc["kick_durations"], *pc["velocity_kick"]],
+                 dtype=np.float32)
+    flags = (WRAP_EPISODE if episode_length > 0 else 0) | (WRAP_AUTORESET if auto_reset else 0)
+    return dict(
+        env_int=np.array([ENV_GO2, n_sub, episode_length, flags, GO2_OBS_DIM, len(GO2_METRICS)], dtype=np.int32),
+        env_ids=ids,
+        env_go2f=f,
+        env_go2i=np.array([dc["action"]["steps"] if dc["action"]["enable"] else 0,
+                           dc["imu"]["steps"] if dc["imu"]["enable"] else 0, int(pc["enable"])], dtype=np.int32),
+        env_go2_scales=np.array([rc["scales"][k] for k in GO2_REWARDS], dtype=np.float32),
+        env_go2_home=home,
+        env_go2_soft=soft,
+        # unused by this env kind but looked up by the generic loaders
+        env_action_scale=np.zeros(m.nu, np.float32), env_ctrl_lo=A["actuator_ctrlrange"][:, 0].astype(np.float32),
+        env_ctrl_hi=A["actuator_ctrlrange"][:, 1].astype(np.float32), env_reset=np.zeros(1, np.float32),
+        env_reward=np.zeros(1, np.float32),
+    )
