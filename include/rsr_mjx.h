@@ -62,6 +62,7 @@ enum rsr_field {
   /* T-shape env info (T_shape_env.py:127-134); present but unused for the cube envs */
   RSR_F_INFO_TARGET_BASE_POS, RSR_F_INFO_TARGET_VERTICAL_POS, RSR_F_INFO_TARGET_W, RSR_F_INFO_NEW_T_POS, RSR_F_INFO_T_POS,
   RSR_F_INFO_XITA,
+  RSR_F_INFO_GO2,          /* Go2 joystick info block, 144 floats (joystick.py:175-196); layout in rsr_mjx_amd/envs/go2.py */
   RSR_F_INFO_STEPS, RSR_F_INFO_TRUNCATION, RSR_F_INFO_EPISODE_DONE, RSR_F_INFO_EPISODE_METRICS,
   RSR_F_FIRST_QPOS, RSR_F_FIRST_QVEL, RSR_F_FIRST_CTRL, RSR_F_FIRST_WARMSTART, RSR_F_FIRST_TIME,
   RSR_F_FIRST_XPOS, RSR_F_FIRST_SITE_XPOS, RSR_F_FIRST_OBS,

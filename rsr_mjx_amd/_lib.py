@@ -11,7 +11,7 @@ FIELDS = [
     "qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos",
     "obs", "reward", "done", "metrics",
     "info_target_pos", "info_new_cube_pos", "info_site_pos", "info_cube_pos", "info_last_action",
-    "info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita",
+    "info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita", "info_go2",
     "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics",
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
     "first_obs", "stats",

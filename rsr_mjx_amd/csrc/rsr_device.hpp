@@ -49,6 +49,8 @@ struct DModel {
   const float *qpos0;
   const int *env_ids;
   const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
+  const float *env_go2f, *env_go2_scales, *env_go2_home, *env_go2_soft;
+  const int *env_go2i;
   float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
   int nfric, nlimit, maxdepth;
@@ -61,6 +63,7 @@ struct Layout {
   int obs, reward, done, metrics;
   int target_pos, new_cube_pos, site_pos, cube_pos, last_action, steps, truncation, episode_done, episode_metrics;
   int target_base_pos, target_vertical_pos, target_w, new_T_pos, T_pos, xita;     // T-shape env info
+  int go2_info;                                                                  // Go2 joystick info block (144 floats)
   int f_qpos, f_qvel, f_ctrl, f_warm, f_time, f_xpos, f_site_xpos, f_obs;
   int stats;
   int rec;            // floats per env (multiple of 16)
@@ -78,9 +81,10 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0>
 struct Dims {
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
+  static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
@@ -212,6 +216,7 @@ struct Smem {
   float egeom[(C::NEG > 0 ? C::NEG : 1) * 3];          // world positions of the env's geoms of interest
   float smat[C::NS * 9], slinvel[C::NS * 3], sangvel[C::NS * 3];   // site frames / object velocities (sensor sources)
   float aforce[C::NU];                                 // actuator_force of the last forward pass
+  float ginfo[C::NINFO > 0 ? C::NINFO : 1];            // env info block staged in LDS for the whole step (Go2)
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
   float M[C::NV * C::LD], T[C::NV * C::LD];
   // contacts (active only)

@@ -17,6 +17,9 @@ namespace rsr {
 // Airbot cube: nq 22, nv 20, nu 5, nbody 14, njnt 10, ngeom 23, nsite 1, npair 45, neq 1, nf 8, nl 8
 using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3>;
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
+// Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
+using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
+                     /*NINFO*/ 144>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
@@ -104,6 +107,82 @@ __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane
   if (lane == 0) rec[L.time] = time;
   for (int t = lane; t < C::NB * 3; t += 64) rec[L.xpos + t] = s.xpos[t];
   for (int t = lane; t < C::NS * 3; t += 64) rec[L.site_xpos + t] = s.spos[t];
+}
+
+// ================================================================ Go2 joystick env (go2/joystick.py)
+// ginfo layout = oracle enum G2_* ; env_go2f / env_go2i / env_ids as documented in rsr_mjx_amd/envs/config.py
+enum { G2_CMD = 0, G2_STEPS_CMD = 3, G2_LAST_ACT = 4, G2_LAST_LAST_ACT = 16, G2_AIR = 28, G2_CONTACT_T = 32, G2_LAST_CONTACT = 36,
+       G2_SWING = 40, G2_ACT_BUF = 44, G2_GYRO_BUF = 92, G2_LINVEL_BUF = 104, G2_GRAV_BUF = 116, G2_STEPS_PERT = 128,
+       G2_PERT_DUR_S = 129, G2_PERT_DUR = 130, G2_SINCE_PERT = 131, G2_PERT_STEPS = 132, G2_PERT_DIR = 133, G2_PERT_MAG = 136,
+       G2_RNG = 137 };
+enum { RW_TRACK_LIN = 0, RW_TRACK_ANG, RW_LIN_VEL_Z, RW_ANG_VEL_XY, RW_ORIENT, RW_DOF_LIMITS, RW_POSE, RW_TERM, RW_STAND_STILL,
+       RW_TORQUES, RW_ACTION_RATE, RW_ENERGY, RW_FEET_CLEAR, RW_FEET_HEIGHT, RW_FEET_SLIP, RW_FEET_AIR, RW_ALL_FEET_AIR,
+       RW_SYM_GAIT, RW_LR_SYM, RW_FB_SYM, RW_FEET_OFF_STILL, RW_COUNT };
+
+// jax.random.split(key, N): every lane receives all N keys (wave-uniform); bits = LDS scratch of >= 2N words
+template <int N>
+__device__ __forceinline__ void tf_split(uint32_t k0, uint32_t k1, uint32_t* bits, int lane, uint32_t (&out)[N][2]) {
+  WSYNC();
+  random_bits(k0, k1, 2 * N, bits, lane);
+  WSYNC();
+#pragma unroll
+  for (int r = 0; r < N; ++r) { out[r][0] = bits[2 * r]; out[r][1] = bits[2 * r + 1]; }
+}
+// jax.random.uniform(key, (n,), lo, hi): lane i < n returns element i
+__device__ __forceinline__ float tf_uniform(uint32_t k0, uint32_t k1, int n, float lo, float hi, uint32_t* bits, int lane) {
+  WSYNC();
+  random_bits(k0, k1, n, bits, lane);
+  WSYNC();
+  return lane < n ? uniform_from_bits(bits[lane], lo, hi) : 0.0f;
+}
+
+struct G2Sens { float gyro[3], linvel[3], gravity[3], up[3], glin[3], gang[3]; };
+
+template <class C>
+__device__ void go2_sensors(const DModel& m, const Smem<C>& s, G2Sens& o) {
+  const int imu = m.env_ids[0];
+  const float* R = &s.smat[9 * imu];
+  V3 w = ld3(&s.sangvel[3 * imu]), v = ld3(&s.slinvel[3 * imu]);
+  // site-frame quantities: R^T x
+  o.gyro[0] = R[0] * w.x + R[3] * w.y + R[6] * w.z; o.gyro[1] = R[1] * w.x + R[4] * w.y + R[7] * w.z; o.gyro[2] = R[2] * w.x + R[5] * w.y + R[8] * w.z;
+  o.linvel[0] = R[0] * v.x + R[3] * v.y + R[6] * v.z; o.linvel[1] = R[1] * v.x + R[4] * v.y + R[7] * v.z; o.linvel[2] = R[2] * v.x + R[5] * v.y + R[8] * v.z;
+  o.gravity[0] = R[0] * 0.0f + R[3] * 0.0f + R[6] * -1.0f; o.gravity[1] = R[1] * 0.0f + R[4] * 0.0f + R[7] * -1.0f; o.gravity[2] = R[2] * 0.0f + R[5] * 0.0f + R[8] * -1.0f;
+  o.up[0] = R[2]; o.up[1] = R[5]; o.up[2] = R[8];
+  o.glin[0] = v.x; o.glin[1] = v.y; o.glin[2] = v.z; o.gang[0] = w.x; o.gang[1] = w.y; o.gang[2] = w.z;
+}
+
+// joystick.py:284-340: 48-dim "state" obs into obs_lds; advances ginfo rng by five splits (wave-cooperative)
+template <class C>
+__device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane) {
+#pragma clang fp contract(off)
+  const float* F = m.env_go2f;
+  const bool idel = m.env_go2i[1] > 0;
+  uint32_t rng0 = __float_as_uint(s.ginfo[G2_RNG]), rng1 = __float_as_uint(s.ginfo[G2_RNG + 1]);
+  uint32_t ks[2][2];
+  const float level = F[2];
+  // order of the draws: gyro, gravity, linvel, joint angles, joint velocities
+  for (int d = 0; d < 5; ++d) {
+    tf_split<2>(rng0, rng1, bits, lane, ks);
+    rng0 = ks[0][0]; rng1 = ks[0][1];
+    const int n = d < 3 ? 3 : 12;
+    float u = tf_uniform(ks[1][0], ks[1][1], n, 0.0f, 1.0f, bits, lane);
+    if (lane < n) {
+      float src, scale; int dst;
+      if (d == 0) { src = idel ? s.ginfo[G2_GYRO_BUF + lane] : sn.gyro[lane]; scale = F[5]; dst = 3 + lane; }
+      else if (d == 1) { src = idel ? s.ginfo[G2_GRAV_BUF + lane] : sn.gravity[lane]; scale = F[6]; dst = 6 + lane; }
+      else if (d == 2) { src = idel ? s.ginfo[G2_LINVEL_BUF + lane] : sn.linvel[lane]; scale = F[7]; dst = lane; }
+      else if (d == 3) { src = s.qpos[7 + lane]; scale = F[3]; dst = 9 + lane; }
+      else { src = s.qvel[6 + lane]; scale = F[4]; dst = 21 + lane; }
+      float a = 2.0f * u; float b = a - 1.0f; float c = b * level; float e = c * scale;
+      float val = src + e;
+      if (d == 3) val = val - m.env_go2_home[7 + lane];
+      obs_lds[dst] = val;
+    }
+  }
+  if (lane < 12) obs_lds[33 + lane] = s.ginfo[G2_LAST_ACT + lane];
+  if (lane < 3) obs_lds[45 + lane] = s.ginfo[G2_CMD + lane];
+  if (lane == 0) { s.ginfo[G2_RNG] = __uint_as_float(rng0); s.ginfo[G2_RNG + 1] = __uint_as_float(rng1); }
+  WSYNC();
 }
 
 // ---------------------------------------------------------------- reset kernel
@@ -403,6 +482,348 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------- Go2 reset kernel (joystick.py:123-203 + wrappers)
+template <class C>
+__global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const float* F = m.env_go2f;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);
+  float* obs_lds = s.T + 64;
+  load_overrides<C>(m, s, a, e, lane);
+  for (int t = lane; t < C::NINFO; t += 64) s.ginfo[t] = 0.0f;
+  uint32_t rng0 = a.keys[2 * e], rng1 = a.keys[2 * e + 1], ks[4][2];
+  if (lane < C::NQ) s.qpos[lane] = m.env_go2_home[lane];
+  if (lane < C::NV) s.qvel[lane] = 0.0f;
+  {
+    uint32_t k2[2][2];
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float dxy = tf_uniform(k2[1][0], k2[1][1], 2, -0.5f, 0.5f, bits, lane);
+    if (lane < 2) s.qpos[lane] = m.env_go2_home[lane] + dxy;
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float yaw = rdlane(tf_uniform(k2[1][0], k2[1][1], 1, -3.14f, 3.14f, bits, lane), 0);
+    if (lane == 0) {
+#pragma clang fp contract(off)
+      float sn = sinf(yaw * 0.5f), cs = cosf(yaw * 0.5f);
+      Q4 q = Q4{m.env_go2_home[3], m.env_go2_home[4], m.env_go2_home[5], m.env_go2_home[6]}, r = Q4{cs, 0.0f * sn, 0.0f * sn, 1.0f * sn};
+      Q4 o;
+      o.w = q.w * r.w - q.x * r.x - q.y * r.y - q.z * r.z;
+      o.x = q.w * r.x + q.x * r.w + q.y * r.z - q.z * r.y;
+      o.y = q.w * r.y - q.x * r.z + q.y * r.w + q.z * r.x;
+      o.z = q.w * r.z + q.x * r.y - q.y * r.x + q.z * r.w;
+      st4(&s.qpos[3], o);
+    }
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float v6 = tf_uniform(k2[1][0], k2[1][1], 6, -0.5f, 0.5f, bits, lane);
+    if (lane < 6) s.qvel[lane] = v6;
+  }
+  WSYNC();
+  if (lane < C::NU) s.ctrl[lane] = s.qpos[7 + lane];          // mjx_env.init(..., ctrl = qpos[7:])
+  WSYNC();
+  float Mrow[C::NV], warm = 0.0f;
+  FwdOut<C> f;
+  PROF_DECL
+  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
+  WSYNC();
+  tf_split<4>(rng0, rng1, bits, lane, ks); rng0 = ks[0][0]; rng1 = ks[0][1];
+  {
+    float t_pert = rdlane(tf_uniform(ks[1][0], ks[1][1], 1, F[17], F[18], bits, lane), 0);
+    float dur = rdlane(tf_uniform(ks[2][0], ks[2][1], 1, F[19], F[20], bits, lane), 0);
+    float mag = rdlane(tf_uniform(ks[3][0], ks[3][1], 1, F[21], F[22], bits, lane), 0);
+    if (lane == 0) {
+      s.ginfo[G2_STEPS_PERT] = rintf(t_pert / F[0]); s.ginfo[G2_PERT_DUR_S] = dur;
+      s.ginfo[G2_PERT_DUR] = rintf(dur / F[0]); s.ginfo[G2_PERT_MAG] = mag;
+    }
+  }
+  {
+    uint32_t k3[3][2];
+    tf_split<3>(rng0, rng1, bits, lane, k3); rng0 = k3[0][0]; rng1 = k3[0][1];
+    float uu = rdlane(tf_uniform(k3[1][0], k3[1][1], 1, 0.0f, 1.0f, bits, lane), 0);
+    float amp = lane < 3 ? F[10 + lane] : 0.0f;
+    float cmd = tf_uniform(k3[2][0], k3[2][1], 3, -amp, amp, bits, lane);
+    if (lane < 3) s.ginfo[G2_CMD + lane] = cmd;
+    if (lane == 0) {
+#pragma clang fp contract(off)
+      float t_cmd = -log1pf(-uu) * F[16];
+      s.ginfo[G2_STEPS_CMD] = rintf(t_cmd / F[0]);
+      s.ginfo[G2_RNG] = __uint_as_float(rng0); s.ginfo[G2_RNG + 1] = __uint_as_float(rng1);
+    }
+  }
+  WSYNC();
+  G2Sens sn;
+  go2_sensors<C>(m, s, sn);
+  go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
+  for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];
+  for (int t = lane; t < C::OBS; t += 64) { rec[L.obs + t] = obs_lds[t]; rec[L.f_obs + t] = obs_lds[t]; }
+  if (lane == 0) {
+    rec[L.reward] = 0.0f; rec[L.done] = 0.0f;
+    for (int i = 0; i < C::NMET; ++i) rec[L.metrics + i] = 0.0f;
+    rec[L.steps] = 0.0f; rec[L.truncation] = 0.0f; rec[L.episode_done] = 0.0f;
+    for (int i = 0; i < 2 + C::NMET; ++i) rec[L.episode_metrics + i] = 0.0f;
+    int* st = reinterpret_cast<int*>(rec + L.stats);
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+    rec[L.f_time] = 0.0f;
+  }
+  for (int t = lane; t < C::NQ; t += 64) rec[L.f_qpos + t] = s.qpos[t];
+  if (lane < C::NV) { rec[L.f_qvel + lane] = s.qvel[lane]; rec[L.f_warm + lane] = warm; }
+  if (lane < C::NU) rec[L.f_ctrl + lane] = s.ctrl[lane];
+  for (int t = lane; t < C::NB * 3; t += 64) rec[L.f_xpos + t] = s.xpos[t];
+  for (int t = lane; t < C::NS * 3; t += 64) rec[L.f_site_xpos + t] = s.spos[t];
+}
+
+// ---------------------------------------------------------------- Go2 step kernel (joystick.py:204-280 + wrappers)
+template <class C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
+void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
+  const float* F = m.env_go2f;
+  const float dt = F[0];
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);
+  float* obs_lds = s.T + 64;
+  float* rwl = s.T + 128;                                   // scaled reward terms staged for the metrics write
+  PROF_DECL
+  for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
+  float warm = 0.0f;
+  if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
+  float time = rec[L.time];
+  load_overrides<C>(m, s, a, e, lane);
+  for (int t = lane; t < C::NINFO; t += 64) s.ginfo[t] = rec[L.go2_info + t];
+  const float done_prev = rec[L.done];
+  float steps = rec[L.steps];
+  if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;
+  const float act_in = lane < C::NU ? a.action[(size_t)e * C::NU + lane] : 0.0f;
+  WSYNC();
+  // ---- action delay FIFO (:207-215) and motor targets (:216) ----
+  const int adel = m.env_go2i[0];
+  float actual = act_in;
+  if (adel > 0) {
+    float shifted = 0.0f;
+    const int nbuf = adel * C::NU;
+    if (lane < C::NU) actual = s.ginfo[G2_ACT_BUF + lane];
+    if (lane < nbuf) shifted = s.ginfo[G2_ACT_BUF + C::NU + lane];
+    WSYNC();
+    if (lane < nbuf) s.ginfo[G2_ACT_BUF + lane] = shifted;
+    if (lane < C::NU) s.ginfo[G2_ACT_BUF + nbuf + lane] = act_in;
+  }
+  if (lane < C::NU) {
+#pragma clang fp contract(off)
+    float sc = actual * F[1];
+    s.ctrl[lane] = m.env_go2_home[7 + lane] + sc;
+  }
+  WSYNC();
+  PROF(PS_LOAD)
+  float Mrow[C::NV];
+  FwdOut<C> f;
+  for (int fr = 0; fr < m.n_frames; ++fr) {
+#ifdef RSR_PROFILE
+    float* dbg = nullptr;
+#else
+    float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
+#endif
+    forward<C>(m, s, lane, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, s, lane, Mrow, f PROF_PASS);
+    time += m.timestep;
+  }
+  // ---- sensors of the last forward pass, IMU FIFOs (:220-235) ----
+  G2Sens sn;
+  go2_sensors<C>(m, s, sn);
+  const int idel = m.env_go2i[1];
+  if (idel > 0) {
+    float v = 0.0f;
+    const int nb = idel * 3;
+    int base = lane < nb ? G2_GYRO_BUF : (lane < 2 * nb ? G2_LINVEL_BUF : G2_GRAV_BUF);
+    int off = lane < nb ? lane : (lane < 2 * nb ? lane - nb : lane - 2 * nb);
+    if (lane < 3 * nb) v = s.ginfo[base + 3 + off];
+    WSYNC();
+    if (lane < 3 * nb) s.ginfo[base + off] = v;
+    if (lane < 3) { s.ginfo[G2_GYRO_BUF + nb + lane] = sn.gyro[lane]; s.ginfo[G2_LINVEL_BUF + nb + lane] = sn.linvel[lane]; s.ginfo[G2_GRAV_BUF + nb + lane] = sn.gravity[lane]; }
+    WSYNC();
+  }
+  // ---- foot contacts (:236-245) ----
+  int contact[4] = {0, 0, 0, 0};
+  for (int i = 0; i < s.ncon; ++i) {
+    if (!(s.cdist[i] < 0.0f)) continue;
+    int g2 = m.pair_geom2[s.cpair[i]], g1 = m.pair_geom1[s.cpair[i]];
+    for (int fi = 0; fi < 4; ++fi) if ((g2 == m.env_ids[6 + fi] && g1 == m.env_ids[5]) || (g1 == m.env_ids[6 + fi] && g2 == m.env_ids[5])) contact[fi] = 1;
+  }
+  int first_contact[4]; float feet_z[4];
+  for (int fi = 0; fi < 4; ++fi) {
+    bool filt = contact[fi] || s.ginfo[G2_LAST_CONTACT + fi] != 0.0f;
+    first_contact[fi] = (s.ginfo[G2_AIR + fi] > 0.0f) && filt;
+    feet_z[fi] = s.spos[3 * m.env_ids[1 + fi] + 2];
+  }
+  WSYNC();
+  if (lane < 4) {
+    s.ginfo[G2_AIR + lane] += dt;
+    s.ginfo[G2_SWING + lane] = fmaxf(s.ginfo[G2_SWING + lane], s.spos[3 * m.env_ids[1 + lane] + 2]);
+  }
+  WSYNC();
+  go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  float done = sn.up[2] < 0.0f ? 1.0f : 0.0f;
+  // ---- rewards (:367-593): scalar algebra on lane 0, evaluated op by op ----
+  float reward = 0.0f;
+  if (lane == 0) {
+#pragma clang fp contract(off)
+    const float* SC = m.env_go2_scales; const float* home = m.env_go2_home;
+    const float* cmd = &s.ginfo[G2_CMD];
+    float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    float moving = cmd_norm > 0.01f ? 1.0f : 0.0f, still = cmd_norm < 0.01f ? 1.0f : 0.0f;
+    float rw[RW_COUNT];
+    {
+      float e0 = cmd[0] - sn.linvel[0], e1 = cmd[1] - sn.linvel[1];
+      rw[RW_TRACK_LIN] = expf(-(e0 * e0 + e1 * e1) / F[8]);
+      float ea = cmd[2] - sn.gyro[2];
+      rw[RW_TRACK_ANG] = expf(-(ea * ea) / F[8]);
+    }
+    rw[RW_LIN_VEL_Z] = sn.glin[2] * sn.glin[2];
+    rw[RW_ANG_VEL_XY] = sn.gang[0] * sn.gang[0] + sn.gang[1] * sn.gang[1];
+    rw[RW_ORIENT] = sn.up[0] * sn.up[0] + sn.up[1] * sn.up[1];
+    {
+      float sa = 0, lim = 0, pose = 0;
+      for (int i = 0; i < 12; ++i) {
+        float q = s.qpos[7 + i], dq = q - home[7 + i];
+        sa += fabsf(dq);
+        float lo_ = q - m.env_go2_soft[i], hi_ = q - m.env_go2_soft[12 + i];
+        lim += -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
+        float w = (i % 3 == 2) ? 0.1f : 1.0f;
+        pose += dq * dq * w;
+      }
+      rw[RW_STAND_STILL] = sa * still; rw[RW_DOF_LIMITS] = lim; rw[RW_POSE] = expf(-pose);
+    }
+    rw[RW_TERM] = done;
+    {
+      float s2 = 0, s1 = 0, en = 0, ar = 0;
+      for (int i = 0; i < 12; ++i) {
+        float t = s.aforce[i]; s2 += t * t; s1 += fabsf(t); en += fabsf(s.qvel[6 + i]) * fabsf(t);
+        float dd = a.action[(size_t)e * C::NU + i] - s.ginfo[G2_LAST_ACT + i]; ar += dd * dd;
+      }
+      rw[RW_TORQUES] = sqrtf(s2) + s1; rw[RW_ENERGY] = en; rw[RW_ACTION_RATE] = ar;
+    }
+    {
+      float slip = 0, clear = 0, height = 0, air = 0; int nair = 0;
+      for (int fi = 0; fi < 4; ++fi) {
+        const int sid = m.env_ids[1 + fi];
+        float vx = s.slinvel[3 * sid], vy = s.slinvel[3 * sid + 1];
+        float v2 = vx * vx + vy * vy;
+        slip += v2 * (float)contact[fi];
+        clear += fabsf(feet_z[fi] - F[9]) * sqrtf(sqrtf(v2));
+        float err = s.ginfo[G2_SWING + fi] / F[9] - 1.0f;
+        height += err * err * (float)first_contact[fi];
+        air += (s.ginfo[G2_AIR + fi] - 0.1f) * (float)first_contact[fi];
+        nair += !contact[fi];
+      }
+      rw[RW_FEET_SLIP] = slip * moving; rw[RW_FEET_CLEAR] = clear; rw[RW_FEET_HEIGHT] = height * moving; rw[RW_FEET_AIR] = air * moving;
+      rw[RW_ALL_FEET_AIR] = (nair >= 3 ? 1.0f : 0.0f) * moving;
+      rw[RW_FEET_OFF_STILL] = (float)nair * still;
+      float p1 = 0, p2 = 0;
+      for (int i = 0; i < 3; ++i) { float x = s.qpos[7 + 3 + i] - s.qpos[7 + 6 + i], y = s.qpos[7 + i] - s.qpos[7 + 9 + i]; p1 += x * x; p2 += y * y; }
+      rw[RW_SYM_GAIT] = (p1 + p2) * moving;
+      const float* at = &s.ginfo[G2_AIR]; const float* ct = &s.ginfo[G2_CONTACT_T];
+      float la = (at[1] + at[3]) / 2.0f, lc = (ct[1] + ct[3]) / 2.0f, ra = (at[0] + at[2]) / 2.0f, rc = (ct[0] + ct[2]) / 2.0f;
+      rw[RW_LR_SYM] = ((la - ra) * (la - ra) + (lc - rc) * (lc - rc)) * moving;
+      float fa = (at[0] + at[1]) / 2.0f, fc = (ct[0] + ct[1]) / 2.0f, ba = (at[2] + at[3]) / 2.0f, bc = (ct[2] + ct[3]) / 2.0f;
+      rw[RW_FB_SYM] = ((fa - ba) * (fa - ba) + (fc - bc) * (fc - bc)) * moving;
+    }
+    for (int k = 0; k < RW_COUNT; ++k) { rw[k] = rw[k] * SC[k]; rwl[k] = rw[k]; }
+    const int order[RW_COUNT] = {RW_TRACK_LIN, RW_TRACK_ANG, RW_LIN_VEL_Z, RW_ANG_VEL_XY, RW_ORIENT, RW_STAND_STILL, RW_TERM, RW_POSE,
+                                 RW_TORQUES, RW_ACTION_RATE, RW_ENERGY, RW_FEET_SLIP, RW_FEET_CLEAR, RW_FEET_HEIGHT, RW_FEET_AIR,
+                                 RW_DOF_LIMITS, RW_ALL_FEET_AIR, RW_SYM_GAIT, RW_LR_SYM, RW_FB_SYM, RW_FEET_OFF_STILL};
+    float total = 0.0f;
+    for (int k = 0; k < RW_COUNT; ++k) total = total + rwl[order[k]];
+    reward = clampf(total * dt, 0.0f, 10000.0f);
+  }
+  reward = rdlane(reward, 0);
+  WSYNC();
+  // ---- bookkeeping (:255-277): last actions, command resampling (threefry), timers ----
+  if (lane < C::NU) { s.ginfo[G2_LAST_LAST_ACT + lane] = s.ginfo[G2_LAST_ACT + lane]; s.ginfo[G2_LAST_ACT + lane] = act_in; }
+  float steps_cmd = s.ginfo[G2_STEPS_CMD] - 1.0f;
+  {
+    uint32_t rng0 = __float_as_uint(s.ginfo[G2_RNG]), rng1 = __float_as_uint(s.ginfo[G2_RNG + 1]);
+    uint32_t k3[3][2], k4[4][2];
+    tf_split<3>(rng0, rng1, bits, lane, k3);
+    tf_split<4>(k3[1][0], k3[1][1], bits, lane, k4);          // sample_command: rng, y_rng, w_rng, z_rng
+    float amp = lane < 3 ? F[10 + lane] : 0.0f;
+    float y = tf_uniform(k4[1][0], k4[1][1], 3, -amp, amp, bits, lane);
+    float uz = tf_uniform(k4[3][0], k4[3][1], 3, 0.0f, 1.0f, bits, lane);
+    float uw = tf_uniform(k4[2][0], k4[2][1], 3, 0.0f, 1.0f, bits, lane);
+    float uu = rdlane(tf_uniform(k3[2][0], k3[2][1], 1, 0.0f, 1.0f, bits, lane), 0);
+    WSYNC();
+    if (lane < 3 && steps_cmd <= 0.0f) {
+#pragma clang fp contract(off)
+      float z = uz < F[13 + lane] ? 1.0f : 0.0f, w = uw < 0.5f ? 1.0f : 0.0f;
+      float x = s.ginfo[G2_CMD + lane];
+      float yz = y * z; float dif = x - yz; float wd = w * dif;
+      s.ginfo[G2_CMD + lane] = x - wd;
+    }
+    if (lane == 0) {
+#pragma clang fp contract(off)
+      if (done != 0.0f || steps_cmd <= 0.0f) { float t1 = -log1pf(-uu) * F[16]; steps_cmd = rintf(t1 / dt); }
+      s.ginfo[G2_STEPS_CMD] = steps_cmd;
+      s.ginfo[G2_RNG] = __uint_as_float(k3[0][0]); s.ginfo[G2_RNG + 1] = __uint_as_float(k3[0][1]);
+    }
+  }
+  if (lane < 4) {
+#pragma clang fp contract(off)
+    float c = (float)contact[lane], nc = 1.0f - c;
+    s.ginfo[G2_AIR + lane] = (s.ginfo[G2_AIR + lane] + dt) * nc;
+    s.ginfo[G2_CONTACT_T + lane] = (s.ginfo[G2_CONTACT_T + lane] + dt) * c;
+    s.ginfo[G2_LAST_CONTACT + lane] = c;
+    s.ginfo[G2_SWING + lane] *= nc;
+  }
+  WSYNC();
+  if (lane == 0) {
+#pragma clang fp contract(off)
+    float swing_mean = (((s.ginfo[G2_SWING] + s.ginfo[G2_SWING + 1]) + s.ginfo[G2_SWING + 2]) + s.ginfo[G2_SWING + 3]) / 4.0f;
+    rwl[RW_COUNT] = swing_mean;
+    for (int k = 0; k < C::NMET; ++k) rec[L.metrics + k] = rwl[k];
+    rec[L.reward] = reward;
+    if (wrap_episode) {
+      steps += 1.0f;
+      bool over = steps >= (float)m.episode_length;
+      rec[L.truncation] = over ? 1.0f - done : 0.0f;
+      float prev_done = rec[L.episode_done];
+      float* em = rec + L.episode_metrics;
+      em[0] = (em[0] + reward) * (1.0f - prev_done);
+      em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
+      for (int i = 0; i < C::NMET; ++i) em[2 + i] = (em[2 + i] + rwl[i]) * (1.0f - prev_done);
+      if (over) done = 1.0f;
+      rec[L.episode_done] = done;
+    }
+    rec[L.steps] = steps;
+    rec[L.done] = done;
+    int* st = reinterpret_cast<int*>(rec + L.stats);
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+  }
+  WSYNC();
+  done = rdlane(done, 0);
+  for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];       // info is never reset by AutoReset
+  if (wrap_autoreset && done != 0.0f) {
+    for (int t = lane; t < L.persist_end; t += 64) rec[t] = rec[L.f_qpos + t];
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = rec[L.f_obs + t];
+  } else {
+    store_pipeline<C>(s, rec, L, lane, warm, time);
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = obs_lds[t];
+  }
+#ifdef RSR_PROFILE
+  PROF(PS_EPILOGUE)
+  if (a.debug && lane == 0) {
+    float* d = a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7200;
+    for (int i = 0; i < PS_COUNT; ++i) d[i] = (float)prof_.acc[i];
+  }
+#endif
+}
+
 }  // namespace rsr
 
 // =====================================================================================
@@ -461,6 +882,7 @@ static Layout make_layout(const rsr_dims& d) {
   L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3); L.last_action = take(1);
   L.target_base_pos = take(3); L.target_vertical_pos = take(3); L.target_w = take(1); L.new_T_pos = take(2);
   L.T_pos = take(3); L.xita = take(1);
+  L.go2_info = take(d.env_kind == rsr::ENV_GO2 ? 144 : 0);
   L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
   L.stats = take(4);
   L.rec = (o + 15) & ~15;
@@ -490,16 +912,18 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
            d.obs_dim == C::OBS && d.nmetrics == C::NMET;
   };
   bool ok = ((d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) && fits(rsr::CubeDims{})) ||
-            (d.env_kind == rsr::ENV_TSHAPE && fits(rsr::TShapeDims{}));
-  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape)"); }
+            (d.env_kind == rsr::ENV_TSHAPE && fits(rsr::TShapeDims{})) || (d.env_kind == rsr::ENV_GO2 && fits(rsr::Go2Dims{}));
+  const int want_condim = d.env_kind == rsr::ENV_GO2 ? 3 : 4;
+  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape, Go2 joystick flat)"); }
   if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
-  for (int i = 0; i < npc; ++i) if (pc[i] != 4) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: only condim-4 contact pairs are built"); }
+  for (int i = 0; i < npc; ++i) if (pc[i] != want_condim) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: contact pairs must all have the condim the kernel is built for (Airbot 4, Go2 3)"); }
   int nea = 0; const int* ea = static_cast<const int*>(m->find("eq_active0", &nea));
   for (int i = 0; i < nea; ++i) if (!ea[i]) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: inactive equality constraints are not built"); }
   if (static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_IMPLICITFAST &&
       static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: integrator"); }
-  if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
+  if (d.env_kind == rsr::ENV_GO2) { using C = rsr::Go2Dims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
+  else if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else { using C = rsr::CubeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   m->layout = make_layout(d);
   d.rec_floats = m->layout.rec;
@@ -532,6 +956,9 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(float, pair_solref) P(float, pair_solimp) P(float, pair_margin) P(float, pair_gap)
   P(int, fric_dofs) P(int, limit_jnts) P(float, qpos0)
   P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
+  if (dm.env_kind == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2) {
+    P(float, env_go2f) P(float, env_go2_scales) P(float, env_go2_home) P(float, env_go2_soft) P(int, env_go2i)
+  } else { dm.env_go2f = dm.env_go2_scales = dm.env_go2_home = dm.env_go2_soft = nullptr; dm.env_go2i = nullptr; }
 #undef P
   auto F = [&](const char* n) { return static_cast<const float*>(m->find(n)); };
   auto I = [&](const char* n) { return static_cast<const int*>(m->find(n)); };
@@ -616,7 +1043,10 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   rsr::StepArgs a = make_args(b);
   a.keys = keys;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
+  if (b->model->dims.env_kind == rsr::ENV_GO2)
+    hipLaunchKernelGGL((rsr::go2_reset_kernel<rsr::Go2Dims>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::Go2Dims>), st, b->dmodel,
+                       b->model->layout, a);
+  else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
     hipLaunchKernelGGL((rsr::reset_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                        b->dmodel, b->model->layout, a);
   else
@@ -632,7 +1062,10 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   rsr::StepArgs a = make_args(b);
   a.action = action;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
+  if (b->model->dims.env_kind == rsr::ENV_GO2)
+    hipLaunchKernelGGL((rsr::go2_step_kernel<rsr::Go2Dims>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::Go2Dims>), st, b->dmodel,
+                       b->model->layout, a);
+  else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
     hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                        b->dmodel, b->model->layout, a);
   else
@@ -671,6 +1104,7 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_INFO_NEW_T_POS: off = L.new_T_pos; w = 2; break;
     case RSR_F_INFO_T_POS: off = L.T_pos; w = 3; break;
     case RSR_F_INFO_XITA: off = L.xita; w = 1; break;
+    case RSR_F_INFO_GO2: off = L.go2_info; w = d.env_kind == rsr::ENV_GO2 ? 144 : 0; break;
     case RSR_F_INFO_STEPS: off = L.steps; w = 1; break;
     case RSR_F_INFO_TRUNCATION: off = L.truncation; w = 1; break;
     case RSR_F_INFO_EPISODE_DONE: off = L.episode_done; w = 1; break;

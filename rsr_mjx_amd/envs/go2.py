@@ -1,0 +1,134 @@
+"""Go2 joystick env on the HIP stepper, mirroring the reference Playground interface
+(mujoco_playground/_src/locomotion/go2/joystick.py `Joystick.reset/step`, `_src/mjx_env.py` `State` with `.data`,
+`_src/registry.py` `load(name, config)`, `_src/wrapper.py` `wrap_for_brax_training`).
+
+Built: task "flat_terrain" (scene_mjx_feetonly_flat_terrain.xml), the 48-dim `state` observation (what
+`SelectObservationWrapper(obs_key="state")`, wrapper.py:77-104, hands to the learner), all 21 reward terms, command
+resampling, action / IMU delay FIFOs, Episode + AutoReset wrappers fused.  Not built yet: `privileged_state`,
+perturbation kicks (disabled in the reference default config), rough terrain (heightfield).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional
+
+from ..mjcf import CompiledModel, compile_mjcf
+from . import config as cfg
+from .airbot import BatchedEnv, State, _ASSETS
+
+
+class Go2Data:
+    """Subset of mjx.Data the env callers read (State.data in the Playground protocol, _src/mjx_env.py:66-74)."""
+
+    def __init__(self, v, dims):
+        self.qpos, self.qvel, self.ctrl = v["qpos"], v["qvel"], v["ctrl"]
+        self.qacc_warmstart, self.time = v["qacc_warmstart"], v["time"][:, 0]
+        self.xpos = v["xpos"].unflatten(1, (dims.nbody, 3))
+        self.site_xpos = v["site_xpos"].unflatten(1, (dims.nsite, 3))
+
+
+# slices of the 144-float info block (rsr_mjx.hip enum G2_*; joystick.py:175-196)
+_INFO = dict(command=(0, 3), steps_until_next_cmd=(3, 4), last_act=(4, 16), last_last_act=(16, 28), feet_air_time=(28, 32),
+             feet_contact_time=(32, 36), last_contact=(36, 40), swing_peak=(40, 44), action_buffer=(44, 92),
+             gyro_buffer=(92, 104), linvel_buffer=(104, 116), gravity_buffer=(116, 128), steps_until_next_pert=(128, 129),
+             pert_duration_seconds=(129, 130), pert_duration=(130, 131), steps_since_last_pert=(131, 132),
+             pert_steps=(132, 133), pert_dir=(133, 136), pert_mag=(136, 137), rng=(137, 139))
+
+
+class Joystick:
+    """Env definition; `batched()` / `wrap_for_brax_training()` give the N-env GPU batch."""
+
+    _obs_dim = cfg.GO2_OBS_DIM
+    _metrics = cfg.GO2_METRICS
+
+    def __init__(self, task: str = "flat_terrain", config: Optional[dict] = None,
+                 config_overrides: Optional[Dict[str, Any]] = None, model_path: Optional[str] = None, device: str = "cuda:0"):
+        if task != "flat_terrain":
+            raise NotImplementedError(f"Go2 task {task!r}: only flat_terrain is built (rough terrain needs the heightfield)")
+        self._config = cfg._merge(config or cfg.GO2_DEFAULT_CONFIG, config_overrides or {})
+        if model_path is None:
+            base = CompiledModel.load(os.path.join(_ASSETS, "go2_flat.npz"))
+        elif model_path.endswith(".npz"):
+            base = CompiledModel.load(model_path)
+        else:
+            base = compile_mjcf(model_path)
+        self.sys = cfg.go2_apply_overrides(base, self._config)          # go2/base.py:25-31
+        self._device = device
+        self._kwargs: Dict[str, Any] = {}
+        self._n_frames = int(round(self._config["ctrl_dt"] / self._config["sim_dt"]))
+        cfg.go2_env_fields(self.sys, self._config)                      # validates the config early
+
+    def _fields_fn(self, sys, episode_length=0, auto_reset=False, **_):
+        return cfg.go2_env_fields(sys, self._config, episode_length, auto_reset)
+
+    @property
+    def observation_size(self) -> int:
+        return self._obs_dim
+
+    @property
+    def action_size(self) -> int:
+        return self.sys.nu
+
+    @property
+    def dt(self) -> float:
+        return float(self._config["ctrl_dt"])
+
+    @property
+    def sim_dt(self) -> float:
+        return float(self._config["sim_dt"])
+
+    @property
+    def n_substeps(self) -> int:
+        return self._n_frames
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def batched(self, num_envs: int, episode_length: int = 0, auto_reset: bool = False, randomization=None) -> "Go2Batched":
+        return Go2Batched(self, num_envs, episode_length, auto_reset, randomization)
+
+
+class Go2Batched(BatchedEnv):
+    def _make_state(self) -> State:
+        v = self._views
+        data = Go2Data(v, self.dims)
+        g = v["info_go2"]
+        info: Dict[str, Any] = {}
+        for k, (a, b) in _INFO.items():
+            t = g[:, a:b]
+            info[k] = t[:, 0] if b - a == 1 else t
+        info["action_buffer"] = g[:, 44:92].unflatten(1, (4, 12))
+        for k, (a, b) in (("gyro_buffer", (92, 104)), ("linvel_buffer", (104, 116)), ("gravity_buffer", (116, 128))):
+            info[k] = g[:, a:b].unflatten(1, (4, 3))
+        metrics = {name: v["metrics"][:, i] for i, name in enumerate(cfg.GO2_METRICS)}
+        if self.episode_length > 0:
+            em = v["info_episode_metrics"]
+            info.update(steps=v["info_steps"][:, 0], truncation=v["info_truncation"][:, 0], episode_done=v["info_episode_done"][:, 0],
+                        episode_metrics={"sum_reward": em[:, 0], "length": em[:, 1],
+                                         **{name: em[:, 2 + i] for i, name in enumerate(cfg.GO2_METRICS)}})
+        if self.auto_reset:
+            info["first_obs"] = v["first_obs"]
+        st = State(pipeline_state=data, obs=v["obs"], reward=v["reward"][:, 0], done=v["done"][:, 0], metrics=metrics, info=info)
+        st.data = data                      # Playground name of the physics state
+        return st
+
+
+def wrap_for_brax_training(env: Joystick, num_envs: int, episode_length: int = 1000, action_repeat: int = 1,
+                           randomization_fn=None) -> Go2Batched:
+    """Counterpart of reference _src/wrapper.py:41-74 (Vmap -> Episode -> AutoReset), fused into the step kernel."""
+    if action_repeat != 1:
+        raise NotImplementedError("action_repeat != 1")
+    if randomization_fn is not None:
+        raise NotImplementedError("Go2 domain randomisation (go2/randomize.py) is not built yet")
+    return env.batched(num_envs, episode_length=episode_length, auto_reset=True)
+
+
+_ENVS = {"Go2JoystickFlatTerrain": dict(task="flat_terrain")}      # _src/locomotion/__init__.py:16-26
+
+
+def load(env_name: str, config: Optional[dict] = None, config_overrides: Optional[Dict[str, Any]] = None, **kw) -> Joystick:
+    """Counterpart of reference _src/registry.py:24-31."""
+    if env_name not in _ENVS:
+        raise ValueError(f"Env '{env_name}' not found. Available envs: {sorted(_ENVS)}")
+    return Joystick(config=config, config_overrides=config_overrides, **_ENVS[env_name], **kw)

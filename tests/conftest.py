@@ -43,6 +43,22 @@ def tshape_model():
     return CompiledModel.load(os.path.join(ASSETS, "airbot_tshape.npz"))
 
 
+@pytest.fixture(scope="session")
+def go2_model():
+    from rsr_mjx_amd.envs import config
+    from rsr_mjx_amd.mjcf import CompiledModel
+    return config.go2_apply_overrides(CompiledModel.load(os.path.join(ASSETS, "go2_flat.npz")), config.GO2_DEFAULT_CONFIG)
+
+
+def make_go2_blob(model, episode_length=0, auto_reset=False, overrides=None):
+    from rsr_mjx_amd.envs import config
+    from rsr_mjx_amd.model import model_fields, pack_blob
+    c = config._merge(config.GO2_DEFAULT_CONFIG, overrides or {})
+    f = model_fields(model)
+    f.update(config.go2_env_fields(model, c, episode_length, auto_reset))
+    return pack_blob(f)
+
+
 def make_blob(model, kind="cube", **env_kwargs):
     from rsr_mjx_amd.envs import config
     from rsr_mjx_amd.model import model_fields, pack_blob

@@ -1,0 +1,214 @@
+"""Go2 joystick env: model structure, reset / PRNG consumption, step bookkeeping and the reward terms that are
+functions of recorded state, restated in numpy from reference go2/joystick.py; plus HIP parity (gpu)."""
+import numpy as np
+import pytest
+
+from conftest import make_go2_blob
+from rsr_mjx_amd import mjcf, prng
+from rsr_mjx_amd.envs import config as cfg
+
+f32 = np.float32
+G = dict(CMD=0, STEPS_CMD=3, LAST_ACT=4, LAST_LAST_ACT=16, AIR=28, CONTACT_T=32, LAST_CONTACT=36, SWING=40, ACT_BUF=44,
+         GYRO_BUF=92, LINVEL_BUF=104, GRAV_BUF=116, STEPS_PERT=128, PERT_DUR_S=129, PERT_DUR=130, PERT_MAG=136, RNG=137)
+
+
+def _key(info):
+    return info[:, G["RNG"]:G["RNG"] + 2].copy().view(np.uint32)
+
+
+def test_go2_model_structure(go2_model):
+    m = go2_model
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.nsite, m.npair) == (19, 18, 12, 14, 13, 39, 6, 4)
+    A = m.arrays
+    assert set(A["pair_kind"].tolist()) == {mjcf.PAIR_PLANE_SPHERE} and set(A["pair_condim"].tolist()) == {3}
+    assert A["opt_integrator"][0] == mjcf.INT_EULER and A["opt_disable_eulerdamp"][0] == 1
+    assert A["opt_iterations"][0] == 1 and A["opt_ls_iterations"][0] == 5 and A["opt_timestep"][0] == 0.004
+    np.testing.assert_allclose(A["dof_damping"], [0] * 6 + [3.0] * 12)                 # base.py:29  (Kd)
+    np.testing.assert_allclose(A["actuator_gainprm"][:, 0], 60.0)                      # base.py:30-31 (Kp)
+    np.testing.assert_allclose(A["actuator_biasprm"][:, 1], -60.0)
+    np.testing.assert_allclose(A["dof_frictionloss"][6:9], [0.3, 0.3, 1.0])
+    np.testing.assert_allclose(A["actuator_forcerange"][:3, 1], [24, 24, 35.55])
+    np.testing.assert_allclose(A["actuator_ctrlrange"][:3], A["jnt_range"][1:4])       # inheritrange
+    floor = m.id("geom", "floor")
+    assert floor == 0 and A["geom_priority"][floor] == 1                               # randomize.py relies on floor = geom 0
+    home = A["key_qpos"][m.names["key"]["home"]]
+    np.testing.assert_allclose(home[:7], [0, 0, 0.278, 1, 0, 0, 0])
+    np.testing.assert_allclose(A["body_mass"].sum(), 6.921 + 4 * (0.678 + 1.152 + 0.241352), rtol=1e-6)
+
+
+def test_go2_reset_follows_joystick(go2_model, oracle_mod):
+    """joystick.py:123-203 with the jax.random call sequence restated on the host PRNG."""
+    orc = oracle_mod.Oracle(make_go2_blob(go2_model))
+    n = 16
+    keys = prng.split(prng.PRNGKey(42), n)
+    st = orc.new_state(n)
+    orc.reset(st, keys)
+    home = go2_model.arrays["key_qpos"][0].astype(f32)
+    for e in range(n):
+        rng = keys[e]
+        rng, key = prng.split(rng, 2)
+        dxy = prng.uniform(key, (2,), -0.5, 0.5)
+        rng, key = prng.split(rng, 2)
+        yaw = prng.uniform(key, (1,), -3.14, 3.14)[0]
+        rng, key = prng.split(rng, 2)
+        v6 = prng.uniform(key, (6,), -0.5, 0.5)
+        q = home.copy(); q[:2] += dxy
+        q[3:7] = [np.cos(f32(yaw * f32(0.5))), 0, 0, np.sin(f32(yaw * f32(0.5)))]
+        np.testing.assert_allclose(st["qpos"][e], q, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(st["qvel"][e, :6], v6)
+        np.testing.assert_array_equal(st["ctrl"][e], home[7:])                          # init(..., ctrl=qpos[7:])
+        rng, k1, k2, k3 = prng.split(rng, 4)
+        info = st["info_go2"][e]
+        assert info[G["STEPS_PERT"]] == np.rint(prng.uniform(k1, (), 1.0, 3.0) / f32(0.02))
+        assert info[G["PERT_DUR_S"]] == prng.uniform(k2, (), 0.05, 0.2)
+        assert info[G["PERT_MAG"]] == prng.uniform(k3, (), 0.0, 3.0)
+        rng, k1, k2 = prng.split(rng, 3)
+        t_cmd = -np.log1p(-prng.uniform(k1, (), 0.0, 1.0)) * f32(12.0)
+        assert abs(info[G["STEPS_CMD"]] - np.rint(f32(t_cmd) / f32(0.02))) <= 1
+        a = np.array([0.8, 0.0, 2.0], f32)
+        np.testing.assert_array_equal(info[G["CMD"]:G["CMD"] + 3], prng.uniform(k2, (3,), -a, a))
+        # _get_obs: five (split, uniform) draws; the IMU FIFOs are zero at reset, so obs[0:9] is pure noise
+        want = np.zeros(48, f32)
+        for idx, nn, scale, src in ((3, 3, 0.2, None), (6, 3, 0.05, None), (0, 3, 0.1, None), (9, 12, 0.03, "q"), (21, 12, 1.5, "v")):
+            rng, nk = prng.split(rng, 2)
+            u = prng.uniform(nk, (nn,), 0.0, 1.0)
+            noise = ((f32(2) * u - f32(1)) * f32(1.0)) * f32(scale)
+            base = np.zeros(nn, f32) if src is None else (st["qpos"][e, 7:] if src == "q" else st["qvel"][e, 6:])
+            want[idx:idx + nn] = base + noise
+        want[9:21] -= home[7:]
+        want[45:48] = info[G["CMD"]:G["CMD"] + 3]
+        np.testing.assert_allclose(st["obs"][e], want, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(_key(st["info_go2"][e:e + 1])[0], rng)
+    assert np.all(st["info_go2"][:, G["ACT_BUF"]:G["RNG"] - 9] == 0)
+
+
+def test_go2_step_bookkeeping_and_state_rewards(go2_model, oracle_mod):
+    """joystick.py:204-280: FIFOs, last actions, command resampling and timers; reward terms that are functions of
+    recorded state (pose, limits, stand_still, action_rate, symmetric_gait, lr/fb symmetry, termination scale)."""
+    orc = oracle_mod.Oracle(make_go2_blob(go2_model))
+    n = 64
+    st = orc.new_state(n)
+    orc.reset(st, prng.split(prng.PRNGKey(7), n))
+    home = go2_model.arrays["key_qpos"][0].astype(f32)
+    soft = np.concatenate([go2_model.arrays["jnt_range"][1:, 0], go2_model.arrays["jnt_range"][1:, 1]]).astype(f32) * f32(0.95)
+    scales = dict(zip(cfg.GO2_REWARDS, cfg.GO2_DEFAULT_CONFIG["reward_config"]["scales"].values()))
+    idx = {k: i for i, k in enumerate(cfg.GO2_REWARDS)}
+    rng = np.random.default_rng(7)
+    resampled = 0
+    for t in range(40):
+        pre = {k: (v.copy() if v is not None else None) for k, v in st.items()}
+        if t == 5:
+            pre["info_go2"][: n // 2, G["STEPS_CMD"]] = 1; st["info_go2"][: n // 2, G["STEPS_CMD"]] = 1     # force a command resample
+        a = np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
+        orc.step(st, a)
+        pi, qi = pre["info_go2"], st["info_go2"]
+        # action FIFO: the applied target is the action of three steps ago
+        np.testing.assert_array_equal(st["ctrl"], home[7:] + pi[:, G["ACT_BUF"]:G["ACT_BUF"] + 12] * f32(0.5))
+        np.testing.assert_array_equal(qi[:, G["ACT_BUF"]:G["ACT_BUF"] + 36], pi[:, G["ACT_BUF"] + 12:G["ACT_BUF"] + 48])
+        np.testing.assert_array_equal(qi[:, G["ACT_BUF"] + 36:G["ACT_BUF"] + 48], a)
+        for b in ("GYRO_BUF", "LINVEL_BUF", "GRAV_BUF"):
+            np.testing.assert_array_equal(qi[:, G[b]:G[b] + 9], pi[:, G[b] + 3:G[b] + 12])
+        np.testing.assert_allclose(np.linalg.norm(qi[:, G["GRAV_BUF"] + 9:G["GRAV_BUF"] + 12], axis=1), 1.0, atol=1e-5)
+        np.testing.assert_array_equal(qi[:, G["LAST_ACT"]:G["LAST_ACT"] + 12], a)
+        np.testing.assert_array_equal(qi[:, G["LAST_LAST_ACT"]:G["LAST_LAST_ACT"] + 12], pi[:, G["LAST_ACT"]:G["LAST_ACT"] + 12])
+        # PRNG: five obs splits, then split(rng, 3); sample_command(key1) and exponential(key2)
+        key = _key(pi)
+        for _ in range(5):
+            key = prng.split(key, 2)[:, 0]
+        ks = prng.split(key, 3)
+        np.testing.assert_array_equal(_key(qi), ks[:, 0])
+        steps = pi[:, G["STEPS_CMD"]] - 1
+        k4 = prng.split(ks[:, 1], 4)
+        amp = np.array([0.8, 0.0, 2.0], f32)
+        y = prng.uniform(k4[:, 1], (3,), -amp, amp)
+        z = prng.uniform(k4[:, 3], (3,), 0.0, 1.0) < np.array([0.8, 0.0, 0.8], f32)
+        w = prng.uniform(k4[:, 2], (3,), 0.0, 1.0) < f32(0.5)
+        x = pi[:, :3]
+        new_cmd = np.where((steps <= 0)[:, None], x - w * (x - y * z), x)
+        np.testing.assert_allclose(qi[:, :3], new_cmd, rtol=1e-6, atol=1e-7)
+        resampled += int((steps <= 0).sum())
+        done = st["done"] != 0
+        fresh = np.rint((-np.log1p(-prng.uniform(ks[:, 2], (), 0.0, 1.0)) * f32(12.0)).astype(f32) / f32(0.02))
+        np.testing.assert_allclose(qi[:, G["STEPS_CMD"]], np.where(done | (steps <= 0), fresh, steps), atol=1)
+        # contact timers: air += 2 dt then zeroed on contact; contact_time += dt, zeroed in the air
+        c = qi[:, G["LAST_CONTACT"]:G["LAST_CONTACT"] + 4]
+        np.testing.assert_allclose(qi[:, G["AIR"]:G["AIR"] + 4], ((pi[:, G["AIR"]:G["AIR"] + 4] + f32(0.02)) + f32(0.02)) * (1 - c), rtol=1e-6)
+        np.testing.assert_allclose(qi[:, G["CONTACT_T"]:G["CONTACT_T"] + 4], (pi[:, G["CONTACT_T"]:G["CONTACT_T"] + 4] + f32(0.02)) * c, rtol=1e-6)
+        # state-only reward terms (metrics hold the scaled values), evaluated with the pre-update command / timers
+        q = st["qpos"][:, 7:]
+        cmd_norm = np.linalg.norm(pi[:, :3], axis=1)
+        moving, still = (cmd_norm > 0.01).astype(f32), (cmd_norm < 0.01).astype(f32)
+        M = st["metrics"]
+        wgt = np.array([1, 1, 0.1] * 4, f32)
+        np.testing.assert_allclose(M[:, idx["pose"]], np.exp(-(((q - home[7:]) ** 2) * wgt).sum(1)) * scales["pose"], rtol=1e-5, atol=1e-7)
+        lim = (-np.clip(q - soft[:12], None, 0) + np.clip(q - soft[12:], 0, None)).sum(1)
+        np.testing.assert_allclose(M[:, idx["dof_pos_limits"]], lim * scales["dof_pos_limits"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(M[:, idx["stand_still"]], np.abs(q - home[7:]).sum(1) * still * scales["stand_still"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(M[:, idx["action_rate"]], ((a - pi[:, G["LAST_ACT"]:G["LAST_ACT"] + 12]) ** 2).sum(1) * scales["action_rate"], rtol=1e-5, atol=1e-7)
+        sym = (((q[:, 3:6] - q[:, 6:9]) ** 2).sum(1) + ((q[:, 0:3] - q[:, 9:12]) ** 2).sum(1)) * moving
+        np.testing.assert_allclose(M[:, idx["symmetric_gait"]], sym * scales["symmetric_gait"], rtol=1e-5, atol=1e-7)
+        at, ct = pi[:, G["AIR"]:G["AIR"] + 4] + f32(0.02), pi[:, G["CONTACT_T"]:G["CONTACT_T"] + 4]
+        lr = (((at[:, 1] + at[:, 3]) / 2 - (at[:, 0] + at[:, 2]) / 2) ** 2 + ((ct[:, 1] + ct[:, 3]) / 2 - (ct[:, 0] + ct[:, 2]) / 2) ** 2) * moving
+        np.testing.assert_allclose(M[:, idx["lr_symmetry"]], lr * scales["lr_symmetry"], rtol=1e-5, atol=1e-7)
+        fb = (((at[:, 0] + at[:, 1]) / 2 - (at[:, 2] + at[:, 3]) / 2) ** 2 + ((ct[:, 0] + ct[:, 1]) / 2 - (ct[:, 2] + ct[:, 3]) / 2) ** 2) * moving
+        np.testing.assert_allclose(M[:, idx["fb_symmetry"]], fb * scales["fb_symmetry"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_array_equal(M[:, idx["termination"]], -st["done"])
+        nair = (1 - c).sum(1)
+        np.testing.assert_allclose(M[:, idx["all_feet_air"]], -(nair >= 3).astype(f32) * moving)
+        np.testing.assert_allclose(M[:, idx["feet_off_ground_when_still"]], -nair * still)
+        # reward = clip(sum of the 21 scaled terms * dt, 0, 1e4); obs tail = last_act (pre-update) and command
+        np.testing.assert_allclose(st["reward"], np.clip(M[:, :21].sum(1) * f32(0.02), 0, 1e4), rtol=2e-5, atol=2e-6)
+        np.testing.assert_array_equal(st["obs"][:, 33:45], pi[:, G["LAST_ACT"]:G["LAST_ACT"] + 12])
+        np.testing.assert_array_equal(st["obs"][:, 45:48], pi[:, :3])
+    assert resampled >= n // 2
+    assert np.median(st["qpos"][:, 2]) > 0.2 and np.isfinite(st["obs"]).all()      # most robots still stand under random actions
+
+
+@pytest.mark.gpu
+def test_go2_hip_parity(go2_model, oracle_mod):
+    """BASELINE configs[3] family (Go2JoystickFlatTerrain): reset bit-exact in the PRNG-only parts, teacher-forced steps.
+    The Go2 solve is intentionally unconverged (iterations=1, ls_iterations=5), so velocities carry the usual fp32 noise."""
+    import torch
+    from rsr_mjx_amd.envs import go2
+    n = 512
+    env = go2.load("Go2JoystickFlatTerrain").batched(n, episode_length=1000, auto_reset=True)
+    assert env.observation_size == 48 and env.action_size == 12 and abs(env.dt - 0.02) < 1e-12
+    orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    o64 = oracle_mod.Oracle(env.blob, "f64"); o64.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(11), n)
+    st = orc.new_state(n)
+    orc.reset(st, keys)
+    state = env.reset(keys)
+    torch.cuda.synchronize()
+    get = lambda k: env.view(k).cpu().numpy().reshape(st[k].shape)
+    for k in ("qvel", "ctrl", "obs", "first_obs"):
+        np.testing.assert_array_equal(get(k), st[k], err_msg=k)
+    np.testing.assert_array_equal(get("info_go2")[:, :137], st["info_go2"][:, :137])
+    np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
+    np.testing.assert_allclose(get("qpos"), st["qpos"], atol=1e-6)
+    fields = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs", "reward", "done", "metrics", "info_go2",
+              "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
+              "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs"]
+    serr = lambda a, b: (np.abs(a.astype(np.float64) - b).reshape(n, -1) / np.maximum(1.0, np.abs(b.astype(np.float64)).reshape(n, -1).max(1, keepdims=True))).max(1)
+    rng = np.random.default_rng(11)
+    for depth in (0, 5, 40):
+        for _ in range(depth):
+            orc.step(st, np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32))
+        for k in fields:
+            env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        st64 = {k: (v.copy() if v is not None else None) for k, v in st.items()}
+        a = np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
+        orc.step(st, a); o64.step(st64, a)
+        state = env.step(state, a)
+        torch.cuda.synchronize()
+        for k in ("done", "info_steps", "info_truncation", "ctrl"):
+            np.testing.assert_array_equal(get(k), st[k], err_msg=k)
+        np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
+        np.testing.assert_array_equal(get("info_go2")[:, :4], st["info_go2"][:, :4])                  # command, timer: PRNG only
+        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel"):
+            eg, ec = serr(get(k), st[k]), serr(st[k], st64[k])
+            allowed = max(1, int(0.01 * n), int(2.0 * np.sum(ec > 1e-5)))
+            assert np.sum(eg > 1e-5) <= allowed, (depth, k, int(np.sum(eg > 1e-5)), allowed)
+            assert eg.max() <= 1e-4 + 3.0 * ec.max(), (depth, k, float(eg.max()), float(ec.max()))
+    assert set(state.info) >= {"command", "last_act", "feet_air_time", "action_buffer", "gyro_buffer", "rng", "steps", "truncation"}
+    assert state.info["action_buffer"].shape == (n, 4, 12) and len(state.metrics) == 22
