@@ -29,7 +29,7 @@ BYTES_PER_ENV_STEP_DR = 1220       # algorithmic bytes per env-s
 BYTES_PER_ENV_STEP = 728           # ... without DR
 
 
-def cpu_baseline(blob: bytes, dr, seconds: float = 12.0):
+def cpu_baseline(blob: bytes, dr, seconds: float = 12.0, nu: int = 5, act_std: float = 1.0):
     """The CPU oracle (kind "port") timed on all host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     from rsr_mjx_amd import prng
@@ -41,7 +41,7 @@ def cpu_baseline(blob: bytes, dr, seconds: float = 12.0):
     st = orc.new_state(n, sub)
     orc.reset(st, prng.split(prng.PRNGKey(123), n), threads)
     rng = np.random.default_rng(1)
-    acts = np.clip(rng.normal(size=(8, n, 5)), -1, 1).astype(np.float32)
+    acts = np.clip(rng.normal(size=(8, n, nu)) * act_std, -1, 1).astype(np.float32)
     for i in range(3):
         orc.step(st, acts[i], threads)
     t0 = time.perf_counter()
@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--no-dr", action="store_true", help="disable domain randomisation")
+    ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2"],
+                    help="cube = BASELINE headline (configs[1] family); tshape / go2 = configs[2] / configs[3] families")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,14 +89,27 @@ def main():
     key_env = prng.split(prng.PRNGKey(0), 3)[1]
     lo, hi = shard_range(total, rank, world)
     keys = shard_keys(key_env, total, rank, world)
-    envdef = AirbotPlayBase(device=f"cuda:{local_rank}")
-    dr = None if args.no_dr else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), total)[lo:hi])
-    env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)   # train.py:47-50
+    if args.workload == "go2":
+        from rsr_mjx_amd.envs import go2
+        envdef = go2.load("Go2JoystickFlatTerrain", device=f"cuda:{local_rank}")
+        dr, ep_len, act_std, wl_name = None, 1000, 0.3, "Go2JoystickFlatTerrain"
+        args.no_dr = True
+    elif args.workload == "tshape":
+        from rsr_mjx_amd.envs.airbot import AirbotTShape
+        envdef = AirbotTShape(device=f"cuda:{local_rank}")
+        dr, ep_len, act_std, wl_name = None, 1200, 1.0, "AirbotPlayBase T_shape_env"
+        args.no_dr = True
+    else:
+        envdef = AirbotPlayBase(device=f"cuda:{local_rank}")
+        dr = None if args.no_dr else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), total)[lo:hi])
+        ep_len, act_std, wl_name = 1200, 1.0, "AirbotPlayBase cube_env"
+    env = envdef.batched(n, episode_length=ep_len, auto_reset=True, randomization=dr)   # train.py:47-50
     state = env.reset(keys)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
     npool = min(args.steps, 256)
-    actions = torch.clamp(torch.randn((npool, n, 5), generator=gen, device=dev), -1.0, 1.0)
+    nu = env.action_size
+    actions = torch.clamp(torch.randn((npool, n, nu), generator=gen, device=dev) * act_std, -1.0, 1.0)
     metrics = torch.zeros(4, device=dev)
 
     def barrier():
@@ -125,12 +140,12 @@ def main():
     env_steps = float(metrics_all[:, 0].sum().item())
 
     if rank == 0:
-        bytes_per = BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR
+        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2044}[args.workload]
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()
         out = {
-            "metric": "env-steps/sec at num_envs=8192, Airbot cube",
+            "metric": "env-steps/sec at num_envs=8192, Airbot cube" if args.workload == "cube" else f"env-steps/sec, {wl_name}",
             "value": env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -143,11 +158,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"AirbotPlayBase cube_env, num_envs={n} per GPU ({total} total), episode_length=1200, "
-                            f"auto-reset, domain randomisation {'off' if args.no_dr else 'on'}, 4 substeps/env-step, "
-                            "actions N(0,1) clipped to +-1",
+                "workload": f"{wl_name}, num_envs={n} per GPU ({total} total), episode_length={ep_len}, "
+                            f"auto-reset, domain randomisation {'off' if args.no_dr else 'on'}, {env.dims.n_frames} substeps/env-step, "
+                            f"actions N(0,{act_std}) clipped to +-1",
                 "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
-                "kernel": "rsr::step_kernel<CubeDims> (one wavefront per env)",
+                "kernel": {"cube": "rsr::step_kernel<CubeDims, ENV_CUBE>", "tshape": "rsr::step_kernel<TShapeDims, ENV_TSHAPE>",
+                           "go2": "rsr::go2_step_kernel<Go2Dims>"}[args.workload] + " (one wavefront per env)",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
                 "mean_newton_iters_last_substep": stats[0], "mean_linesearch_iters_last_substep": stats[1],
                 "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3],
@@ -161,7 +177,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env.blob, dr)
+            out["cpu_baseline"] = cpu_baseline(env.blob, dr, nu=nu, act_std=act_std)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
