@@ -46,6 +46,10 @@ struct DModel {
   const int *pair_geom1, *pair_geom2, *pair_kind, *pair_condim;
   const float *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   const int *fric_dofs, *limit_jnts;
+  // flattened one-level tables (rsr_mjx_amd/model.py: flattened_tables)
+  const int *pair_b1, *pair_b2, *pair_root1, *pair_root2, *dof_rootid, *dof_jtype, *dof_k, *dof_act, *dof_afl, *body_jtype, *body_qposadr;
+  const unsigned *pair_mask1, *pair_mask2;
+  const float *pair_tw, *pair_incl, *dof_afrange, *body_jpos, *body_jaxis;
   const float *qpos0;
   const int *env_ids;
   const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
@@ -81,10 +85,14 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0>
 struct Dims {
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
+  // dofs [ISO0, ISO1) never share a constraint row or a kinematic chain with the others (the Airbot target body: it only
+  // touches static geoms), so those entries of M, H and their Cholesky factors are structural zeros; checked on the host.
+  static constexpr int ISO0 = ISO0_, ISO1 = ISO1_;
+  static constexpr bool coupled(int i, int j) { return (i >= ISO0_ && i < ISO1_) == (j >= ISO0_ && j < ISO1_); }
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
@@ -247,8 +255,9 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
   V3 bp = ld3(&m.body_pos[3 * b]);
   Q4 bq = ld4(&m.body_quat[4 * b]);
   V3 lp = bp; Q4 lq = bq;
-  if (lane < C::NB && m.body_jntnum[b] > 0) {
-    int j = m.body_jntadr[b], qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
+  const int jt = lane < C::NB ? m.body_jtype[b] : -1;
+  if (jt >= 0) {
+    const int qa = m.body_qposadr[b];
     if (jt == JNT_FREE) {
       lp = ld3(&s.qpos[qa]);
       lq = ld4(&s.qpos[qa + 3]);
@@ -257,7 +266,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
       else { float inv = 1.0f / n; lq = Q4{lq.w * inv, lq.x * inv, lq.y * inv, lq.z * inv}; }
       st4(&s.qpos[qa + 3], lq);                    // MJX writes the normalised quaternion back
     } else {
-      V3 jp = ld3(&m.jnt_pos[3 * j]), jax = ld3(&m.jnt_axis[3 * j]);
+      V3 jp = ld3(&m.body_jpos[3 * b]), jax = ld3(&m.body_jaxis[3 * b]);
       float dq = s.qpos[qa] - m.qpos0[qa];
       if (jt == JNT_HINGE) {
         float sn, cs;
@@ -365,8 +374,8 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   }
   // cdof: lane = dof
   if (lane < C::NV) {
-    int i = lane, j = m.dof_jntid[i], b = m.dof_bodyid[i], jt = m.jnt_type[j], k = i - m.jnt_dofadr[j];
-    V3 off = ld3(&s.com[3 * m.body_rootid[b]]) - ld3(&s.x.a.xanchor[3 * j]);
+    int i = lane, j = m.dof_jntid[i], b = m.dof_bodyid[i], jt = m.dof_jtype[i], k = m.dof_k[i];
+    V3 off = ld3(&s.com[3 * m.dof_rootid[i]]) - ld3(&s.x.a.xanchor[3 * j]);
     V3 ang, lin;
     if (jt == JNT_FREE) {
       if (k < 3) { ang = v3(0, 0, 0); lin = v3(k == 0, k == 1, k == 2); }
@@ -418,6 +427,7 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
     a[k] = (lane == k) ? inv : a[k] * inv;      // column k of L below the diagonal; the diagonal slot keeps 1/L[k][k]
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {
+      if (!C::coupled(j, k)) continue;          // L[j][k] is a structural zero (folds at compile time)
       float ljk = rdlane(a[k], j);
       a[j] -= a[k] * ljk;                       // rows i >= j use it; others hold garbage never read
     }
@@ -708,7 +718,7 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane)
   float incl = 0.0f;
   if (lane < C::NP) {
     int p = lane, g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], kind = m.pair_kind[p];
-    incl = m.pair_margin[p] - m.pair_gap[p];
+    incl = m.pair_incl[p];
     V3 p1 = ld3(&s.x.a.gpos[3 * g1]), p2 = ld3(&s.x.a.gpos[3 * g2]);
     if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, &s.x.a.gmat[9 * g1], p2, &s.x.a.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), pts, job);
     else if (kind == PAIR_BOX_BOX)
@@ -777,8 +787,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   // cdof_dot[i] = (velocity of the chain before dof i) x cdof[i]
   if (lane < C::NV) {
     unsigned mask = m.dof_velmask[lane];
-    int j = m.dof_jntid[lane];
-    bool free_trans = (m.jnt_type[j] == JNT_FREE) && (lane - m.jnt_dofadr[j] < 3);
+    bool free_trans = (m.dof_jtype[lane] == JNT_FREE) && (m.dof_k[lane] < 3);
     float v[6] = {0, 0, 0, 0, 0, 0};
     while (mask) {
       int i = __builtin_ctz(mask); mask &= mask - 1;
@@ -833,23 +842,21 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
 #pragma unroll
     for (int c = 0; c < 6; ++c) bias += s.cdof[6 * i + c] * s.x.a.cfrcsum[6 * b + c];
     float passive = -s.damp[i] * qvel_i;
-    // actuation: joint transmissions; lanes scan the (few) actuators for their dof
+    // actuation: joint transmission, at most one actuator per dof (dof_act)
     float act = 0;
-    for (int u = 0; u < C::NU; ++u) {
-      int j = m.actuator_trnid[u];
-      if (m.jnt_dofadr[j] != i) continue;
+    const int u = m.dof_act[i];
+    if (u >= 0) {
       float gear = m.actuator_gear[u];
-      float length = s.qpos[m.jnt_qposadr[j]] * gear, velocity = qvel_i * gear;
+      float length = s.qpos[m.jnt_qposadr[m.dof_jntid[i]]] * gear, velocity = qvel_i * gear;
       float ctrl = s.ctrl[u];
       if (m.actuator_ctrllimited[u]) ctrl = clampf(ctrl, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
       float force = m.actuator_gainprm[3 * u] * ctrl + m.actuator_biasprm[3 * u] + m.actuator_biasprm[3 * u + 1] * length +
                     m.actuator_biasprm[3 * u + 2] * velocity;
       if (m.actuator_forcelimited[u]) force = clampf(force, m.actuator_forcerange[2 * u], m.actuator_forcerange[2 * u + 1]);
       s.aforce[u] = force;
-      act += gear * force;
+      act = gear * force;
     }
-    int j = m.dof_jntid[i];
-    if (m.jnt_actfrclimited[j]) act = clampf(act, m.jnt_actfrcrange[2 * j], m.jnt_actfrcrange[2 * j + 1]);
+    if (m.dof_afl[i]) act = clampf(act, m.dof_afrange[2 * i], m.dof_afrange[2 * i + 1]);
     smooth = passive - bias + act;
   }
   (void)ctrl_u;
@@ -932,13 +939,12 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
-    int p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-    int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+    int p = s.cpair[c];
     V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
     make_frame(n, nn, t1, t2);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
-    float in1 = ((m.body_dofmask[b1] >> i) & 1) ? 1.0f : 0.0f, in2 = ((m.body_dofmask[b2] >> i) & 1) ? 1.0f : 0.0f;
-    V3 o1 = pos - ld3(&s.com[3 * m.body_rootid[b1]]), o2 = pos - ld3(&s.com[3 * m.body_rootid[b2]]);
+    float in1 = ((m.pair_mask1[p] >> i) & 1) ? 1.0f : 0.0f, in2 = ((m.pair_mask2[p] >> i) & 1) ? 1.0f : 0.0f;
+    V3 o1 = pos - ld3(&s.com[3 * m.pair_root1[p]]), o2 = pos - ld3(&s.com[3 * m.pair_root2[p]]);
     V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
     V3 jr = ang * (in2 - in1);
     float* Jr = &s.x.b.J[(r_con + C::NBC * c) * LD + i];
@@ -981,12 +987,12 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
         pos = fminf(q - m.jnt_range[2 * j], m.jnt_range[2 * j + 1] - q) - m.jnt_margin[j];
         invw = m.dof_invweight0[m.jnt_dofadr[j]]; sr0 = m.jnt_solref[2 * j]; sr1 = m.jnt_solref[2 * j + 1]; si = &m.jnt_solimp[5 * j];
       } else {
-        int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-        pos = s.cdist[c] - (m.pair_margin[p] - m.pair_gap[p]);
+        int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c];
+        pos = s.cdist[c] - m.pair_incl[p];
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];
         o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
-        float tw = m.body_invweight0[2 * m.geom_bodyid[g1]] + m.body_invweight0[2 * m.geom_bodyid[g2]];
+        float tw = m.pair_tw[p];
         invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / m.impratio;
         sr0 = m.pair_solref[2 * p]; sr1 = m.pair_solref[2 * p + 1]; si = &m.pair_solimp[5 * p];
       }

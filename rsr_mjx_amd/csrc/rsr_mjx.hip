@@ -15,7 +15,8 @@
 namespace rsr {
 
 // Airbot cube: nq 22, nv 20, nu 5, nbody 14, njnt 10, ngeom 23, nsite 1, npair 45, neq 1, nf 8, nl 8
-using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3>;
+using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3, 0, 0, 4, 0,
+                      /*ISO: the target body's free joint, dofs 8..13*/ 8, 14>;
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
@@ -922,6 +923,29 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   for (int i = 0; i < nea; ++i) if (!ea[i]) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: inactive equality constraints are not built"); }
   if (static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_IMPLICITFAST &&
       static_cast<const int*>(m->find("opt_integrator"))[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: integrator"); }
+  {  // the kernels treat dofs [ISO0, ISO1) as decoupled from the rest: no chain, pair or equality may straddle the range
+    const int iso0 = (d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) ? rsr::CubeDims::ISO0 : 0;
+    const int iso1 = (d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) ? rsr::CubeDims::ISO1 : 0;
+    if (iso1 > iso0) {
+      const unsigned iso = ((1u << iso1) - 1u) & ~((1u << iso0) - 1u);
+      auto straddles = [&](unsigned mask) { return (mask & iso) && (mask & ~iso); };
+      int nb = 0, np1 = 0, np2 = 0, ne1 = 0, ne2 = 0, nj = 0;
+      const unsigned* bm = static_cast<const unsigned*>(m->find("body_dofmask", &nb));
+      const unsigned* m1 = static_cast<const unsigned*>(m->find("pair_mask1", &np1));
+      const unsigned* m2 = static_cast<const unsigned*>(m->find("pair_mask2", &np2));
+      const int* e1 = static_cast<const int*>(m->find("eq_obj1id", &ne1));
+      const int* e2 = static_cast<const int*>(m->find("eq_obj2id", &ne2));
+      const int* jd = static_cast<const int*>(m->find("jnt_dofadr", &nj));
+      bool bad = !bm || !m1 || !m2 || np1 != np2 || !jd;
+      for (int i = 0; !bad && i < nb; ++i) bad = straddles(bm[i]);
+      for (int i = 0; !bad && i < np1; ++i) bad = straddles(m1[i] | m2[i]);
+      for (int i = 0; !bad && e1 && e2 && i < ne1 && i < ne2; ++i) {
+        unsigned mk = (e1[i] >= 0 && e1[i] < nj ? 1u << jd[e1[i]] : 0u) | (e2[i] >= 0 && e2[i] < nj ? 1u << jd[e2[i]] : 0u);
+        bad = straddles(mk);
+      }
+      if (bad) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the kernel assumes the target body's dofs share no chain, contact pair or equality with other dofs"); }
+    }
+  }
   if (d.env_kind == rsr::ENV_GO2) { using C = rsr::Go2Dims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else { using C = rsr::CubeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
@@ -955,6 +979,9 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(int, pair_geom1) P(int, pair_geom2) P(int, pair_kind) P(int, pair_condim)
   P(float, pair_solref) P(float, pair_solimp) P(float, pair_margin) P(float, pair_gap)
   P(int, fric_dofs) P(int, limit_jnts) P(float, qpos0)
+  P(int, pair_b1) P(int, pair_b2) P(int, pair_root1) P(int, pair_root2) P(unsigned, pair_mask1) P(unsigned, pair_mask2)
+  P(float, pair_tw) P(float, pair_incl) P(int, dof_rootid) P(int, dof_jtype) P(int, dof_k) P(int, dof_act) P(int, dof_afl)
+  P(float, dof_afrange) P(int, body_jtype) P(int, body_qposadr) P(float, body_jpos) P(float, body_jaxis)
   P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
   if (dm.env_kind == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2) {
     P(float, env_go2f) P(float, env_go2_scales) P(float, env_go2_home) P(float, env_go2_soft) P(int, env_go2i)

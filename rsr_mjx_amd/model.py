@@ -83,6 +83,52 @@ def model_fields(m: CompiledModel) -> Dict[str, np.ndarray]:
     return f
 
 
+def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np.ndarray]:
+    """One-level look-up tables for the kernel's hot loops (a chain pair -> geom -> body -> mask of dependent global
+    loads costs three L1/L2 round trips per trip of the loop; these tables make it one).
+
+      pair_b1/b2, pair_root1/2, pair_mask1/2 : bodies, tree roots and chain dof masks of the two geoms of a pair
+      pair_tw    : body_invweight0[b1,0] + body_invweight0[b2,0] ; pair_incl : margin - gap
+      dof_rootid, dof_jtype, dof_k            : tree root of the dof's body, joint type, index of the dof inside its joint
+      dof_act                                 : actuator driving the dof (-1: none; at most one per dof)
+      dof_afl, dof_afrange                    : joint actuatorfrcrange, per dof
+      body_jtype, body_qposadr, body_jpos, body_jaxis : the (single) joint of a body, -1 type when it has none
+    """
+    A = m.arrays
+    nv, nb, npair = m.nv, m.nbody, m.npair
+    gb = A["geom_bodyid"]
+    b1, b2 = gb[A["pair_geom1"]], gb[A["pair_geom2"]]
+    out = dict(
+        pair_b1=b1.astype(np.int32), pair_b2=b2.astype(np.int32),
+        pair_root1=A["body_rootid"][b1].astype(np.int32), pair_root2=A["body_rootid"][b2].astype(np.int32),
+        pair_mask1=body_dofmask[b1].astype(np.uint32).view(np.int32), pair_mask2=body_dofmask[b2].astype(np.uint32).view(np.int32),
+        pair_tw=(A["body_invweight0"][b1, 0] + A["body_invweight0"][b2, 0]).astype(np.float32),
+        pair_incl=(A["pair_margin"] - A["pair_gap"]).astype(np.float32),
+    )
+    jid = A["dof_jntid"]
+    out["dof_rootid"] = A["body_rootid"][A["dof_bodyid"]].astype(np.int32)
+    out["dof_jtype"] = A["jnt_type"][jid].astype(np.int32)
+    out["dof_k"] = (np.arange(nv) - A["jnt_dofadr"][jid]).astype(np.int32)
+    act = np.full(nv, -1, dtype=np.int32)
+    for u in range(m.nu):
+        d = int(A["jnt_dofadr"][A["actuator_trnid"][u]])
+        if act[d] >= 0:
+            raise NotImplementedError("two actuators on one dof")
+        act[d] = u
+    out["dof_act"] = act
+    out["dof_afl"] = A["jnt_actfrclimited"][jid].astype(np.int32)
+    out["dof_afrange"] = A["jnt_actfrcrange"][jid].astype(np.float32).reshape(nv, 2)
+    bj = np.full(nb, -1, dtype=np.int32)
+    bq = np.zeros(nb, dtype=np.int32)
+    bjp, bja = np.zeros((nb, 3), np.float32), np.zeros((nb, 3), np.float32)
+    for b in range(nb):
+        if A["body_jntnum"][b] > 0:
+            j = int(A["body_jntadr"][b])
+            bj[b], bq[b], bjp[b], bja[b] = A["jnt_type"][j], A["jnt_qposadr"][j], A["jnt_pos"][j], A["jnt_axis"][j]
+    out.update(body_jtype=bj, body_qposadr=bq, body_jpos=bjp, body_jaxis=bja)
+    return out
+
+
 def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
     """Bitmask tables that let the kernel replace the tree recursions of the reference's
     scan.body_tree passes by independent per-lane loops (all models here have nv, nbody <= 32).
@@ -134,6 +180,7 @@ def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
     for b in range(1, nb):
         depth[b] = depth[int(A["body_parentid"][b])] + 1
     as_i32 = lambda a: a.astype(np.uint32).view(np.int32)
-    return dict(dof_ancmask=as_i32(anc), dof_velmask=as_i32(vel), body_dofmask=as_i32(bdof),
+    flat = flattened_tables(m, bdof)
+    return dict(**flat, dof_ancmask=as_i32(anc), dof_velmask=as_i32(vel), body_dofmask=as_i32(bdof),
                 body_submask=as_i32(sub), fric_dofs=fric, limit_jnts=lim, body_depth=depth,
                 counts2=np.array([len(fric), len(lim), int(depth.max()), int(A["body_jntnum"].max())], dtype=np.int32))
