@@ -93,6 +93,9 @@ struct Dims {
   // touches static geoms), so those entries of M, H and their Cholesky factors are structural zeros; checked on the host.
   static constexpr int ISO0 = ISO0_, ISO1 = ISO1_;
   static constexpr bool coupled(int i, int j) { return (i >= ISO0_ && i < ISO1_) == (j >= ISO0_ && j < ISO1_); }
+  // with an isolated range the dofs before it, inside it and after it are three separate kinematic trees (checked on the
+  // host): the mass matrix alone is block diagonal over them
+  static constexpr bool same_tree(int i, int j) { return ISO1_ <= ISO0_ || ((i >= ISO0_) + (i >= ISO1_)) == ((j >= ISO0_) + (j >= ISO1_)); }
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
@@ -416,7 +419,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
 // in-register Cholesky, lane i = row i.  a[] holds row i (lower part used); on return a[] holds
 // row i of L, lt[] holds row i of L^T (column i of L) fetched through the LDS scratch T.
 // =====================================================================================
-template <class C>
+template <class C, bool MASS_ONLY = false>
 __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV], float* T, int lane) {
 #pragma unroll
   for (int k = 0; k < C::NV; ++k) {
@@ -427,7 +430,7 @@ __device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV
     a[k] = (lane == k) ? inv : a[k] * inv;      // column k of L below the diagonal; the diagonal slot keeps 1/L[k][k]
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {
-      if (!C::coupled(j, k)) continue;          // L[j][k] is a structural zero (folds at compile time)
+      if (!(MASS_ONLY ? C::same_tree(j, k) : C::coupled(j, k))) continue;   // L[j][k] is a structural zero (folds at compile time)
       float ljk = rdlane(a[k], j);
       a[j] -= a[k] * ljk;                       // rows i >= j use it; others hold garbage never read
     }

@@ -937,7 +937,8 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
       const int* e2 = static_cast<const int*>(m->find("eq_obj2id", &ne2));
       const int* jd = static_cast<const int*>(m->find("jnt_dofadr", &nj));
       bool bad = !bm || !m1 || !m2 || np1 != np2 || !jd;
-      for (int i = 0; !bad && i < nb; ++i) bad = straddles(bm[i]);
+      const unsigned low = (1u << iso0) - 1u;      // the trees before / after the range must be separate too (mass matrix blocks)
+      for (int i = 0; !bad && i < nb; ++i) bad = straddles(bm[i]) || ((bm[i] & low) && (bm[i] & ~low));
       for (int i = 0; !bad && i < np1; ++i) bad = straddles(m1[i] | m2[i]);
       for (int i = 0; !bad && e1 && e2 && i < ne1 && i < ne2; ++i) {
         unsigned mk = (e1[i] >= 0 && e1[i] < nj ? 1u << jd[e1[i]] : 0u) | (e2[i] >= 0 && e2[i] < nj ? 1u << jd[e2[i]] : 0u);

@@ -398,7 +398,7 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   float a[C::NV], lt[C::NV];
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] : 0.0f;
-  chol_factor<C>(a, lt, s.T, lane);
+  chol_factor<C, true>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, fs, lane) : 0.0f;
   PROF(PS_CHOLM)
   collision<C>(m, s, lane);
@@ -466,7 +466,7 @@ __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane,
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] + (j == lane ? dd : 0.0f) : 0.0f;
-    chol_factor<C>(a, lt, s.T, lane);
+    chol_factor<C, true>(a, lt, s.T, lane);
     qacc = lane < C::NV ? chol_solve<C>(a, lt, f.fsmooth + f.qfc, lane) : 0.0f;
   }
   WSYNC();
