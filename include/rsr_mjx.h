@@ -86,6 +86,18 @@ void rsr_batch_destroy(rsr_batch* b);
 int rsr_batch_set_dr(rsr_batch* b, const float* geom_friction, const float* body_mass,
                      const float* dof_damping, const float* dof_frictionloss);
 
+/* One per-env model leaf at a time, covering the Go2 randomisation too (reference
+ * ppo_train/go2_training/mujoco_playground/_src/locomotion/go2/randomize.py:6-109: geom_friction, body_ipos, body_mass, qpos0,
+ * dof_frictionloss, dof_armature, actuator_gainprm, actuator_biasprm, dof_damping).  Device pointer [num_envs, width] with
+ * width = ngeom*3, nbody, nv, nv, nbody*3, nq, nv, nu*3, nu*3 in enum order; NULL restores the model's value.  The last
+ * five are built into the Go2 kernels only (RSR_ERR_UNSUPPORTED elsewhere).  Pointers are borrowed. */
+enum rsr_dr_field {
+  RSR_DR_GEOM_FRICTION = 0, RSR_DR_BODY_MASS, RSR_DR_DOF_DAMPING, RSR_DR_DOF_FRICTIONLOSS,
+  RSR_DR_BODY_IPOS, RSR_DR_QPOS0, RSR_DR_DOF_ARMATURE, RSR_DR_ACTUATOR_GAINPRM, RSR_DR_ACTUATOR_BIASPRM,
+  RSR_DR_COUNT
+};
+int rsr_batch_set_dr_field(rsr_batch* b, int dr_field, const float* dev_values);
+
 /* keys: device uint32 [num_envs, 2] (jax.random key data).  Writes every record field. */
 int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream);
 

@@ -24,7 +24,9 @@ _BATCH_FIELDS = [
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
     "first_obs",
     "dr_geom_friction", "dr_body_mass", "dr_dof_damping", "dr_dof_frictionloss",
+    "dr_body_ipos", "dr_qpos0", "dr_dof_armature", "dr_gainprm", "dr_biasprm",
 ]
+_DR_KEYS = [f for f in _BATCH_FIELDS if f.startswith("dr_")]
 
 
 class _OBatch(C.Structure):
@@ -99,7 +101,7 @@ class Oracle:
             first_time=z(), first_xpos=z(self.nbody, 3), first_site_xpos=z(self.nsite, 3), first_obs=z(self.obs_dim),
             stats=np.zeros((n, 4), dtype=np.int32),
         )
-        for k in ("dr_geom_friction", "dr_body_mass", "dr_dof_damping", "dr_dof_frictionloss"):
+        for k in _DR_KEYS:
             st[k] = None if dr is None or dr.get(k[3:]) is None else np.ascontiguousarray(dr[k[3:]], dtype=np.float32).reshape(n, -1)
         return st
 

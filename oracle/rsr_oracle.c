@@ -222,6 +222,8 @@ typedef struct {
   real qpos[NQ_MAX], qvel[NV_MAX], ctrl[NU_MAX], qacc_warmstart[NV_MAX], time;
   /* per-env model overrides (domain randomisation) */
   real geom_friction[NGEOM_MAX * 3], body_mass[NBODY_MAX], dof_damping[NV_MAX], dof_frictionloss[NV_MAX];
+  /* the further leaves the Go2 randomisation makes per-env (go2/randomize.py:6-109) */
+  real body_ipos[NBODY_MAX * 3], qpos0[NQ_MAX], dof_armature[NV_MAX], gainprm[NU_MAX * 3], biasprm[NU_MAX * 3];
   /* position stage */
   real xpos[NBODY_MAX * 3], xquat[NBODY_MAX * 4], xmat[NBODY_MAX * 9], xipos[NBODY_MAX * 3], ximat[NBODY_MAX * 9];
   real xanchor[NJNT_MAX * 3], xaxis[NJNT_MAX * 3];
@@ -289,13 +291,13 @@ static void kinematics(const omodel *m, odata *d) {
         v3copy(&d->xaxis[3 * j], axis);
         if (m->jnt_type[j] == JNT_HINGE) {
           real qloc[4], q2[4], r[3];
-          axis_angle_to_quat(qloc, ja, d->qpos[qa] - (real)m->qpos0[qa]);
+          axis_angle_to_quat(qloc, ja, d->qpos[qa] - d->qpos0[qa]);
           quat_mul(q2, quat, qloc);
           for (int c = 0; c < 4; c++) quat[c] = q2[c];
           rotate(r, jp_, quat);
           for (int c = 0; c < 3; c++) pos[c] = anchor[c] - r[c];
         } else { /* slide */
-          real dq = d->qpos[qa] - (real)m->qpos0[qa];
+          real dq = d->qpos[qa] - d->qpos0[qa];
           for (int c = 0; c < 3; c++) pos[c] += axis[c] * dq;
         }
       }
@@ -305,7 +307,7 @@ static void kinematics(const omodel *m, odata *d) {
   }
   for (int b = 0; b < m->nbody; b++) {
     quat_to_mat(&d->xmat[9 * b], &d->xquat[4 * b]);
-    real ip[3] = {m->body_ipos[3 * b], m->body_ipos[3 * b + 1], m->body_ipos[3 * b + 2]}, t[3], q[4];
+    real ip[3] = {d->body_ipos[3 * b], d->body_ipos[3 * b + 1], d->body_ipos[3 * b + 2]}, t[3], q[4];
     real iq[4] = {m->body_iquat[4 * b], m->body_iquat[4 * b + 1], m->body_iquat[4 * b + 2], m->body_iquat[4 * b + 3]};
     mat_mulv(t, &d->xmat[9 * b], ip);
     for (int c = 0; c < 3; c++) d->xipos[3 * b + c] = d->xpos[3 * b + c] + t[c];
@@ -471,7 +473,7 @@ static void crb_and_factor(const omodel *m, odata *d) {
       d->M[i * nv + j] = s;
       d->M[j * nv + i] = s;
     }
-    d->M[i * nv + i] += m->dof_armature[i];
+    d->M[i * nv + i] += d->dof_armature[i];
   }
   cholesky(d->L, d->M, nv, nv);
 }
@@ -838,8 +840,8 @@ static void make_constraint(const omodel *m, odata *d) {
     if (!m->eq_active0[e]) continue;
     int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
     const float *data = &m->eq_data[5 * e];
-    real pos1 = d->qpos[m->jnt_qposadr[j1]] - (real)m->qpos0[m->jnt_qposadr[j1]];
-    real dif = j2 >= 0 ? d->qpos[m->jnt_qposadr[j2]] - (real)m->qpos0[m->jnt_qposadr[j2]] : 0;
+    real pos1 = d->qpos[m->jnt_qposadr[j1]] - d->qpos0[m->jnt_qposadr[j1]];
+    real dif = j2 >= 0 ? d->qpos[m->jnt_qposadr[j2]] - d->qpos0[m->jnt_qposadr[j2]] : 0;
     real pw[5] = {1, dif, dif * dif, dif * dif * dif, dif * dif * dif * dif};
     real poly = 0, deriv = 0;
     for (int k = 0; k < 5; k++) poly += (real)data[k] * pw[k];
@@ -988,8 +990,7 @@ static void fwd_velocity_actuation(const omodel *m, odata *d) {
     real length = d->qpos[qa] * gear, velocity = d->qvel[da] * gear;
     real ctrl = d->ctrl[u];
     if (m->actuator_ctrllimited[u]) ctrl = clampr(ctrl, m->actuator_ctrlrange[2 * u], m->actuator_ctrlrange[2 * u + 1]);
-    real force = (real)m->actuator_gainprm[3 * u] * ctrl + (real)m->actuator_biasprm[3 * u] +
-                 (real)m->actuator_biasprm[3 * u + 1] * length + (real)m->actuator_biasprm[3 * u + 2] * velocity;
+    real force = d->gainprm[3 * u] * ctrl + d->biasprm[3 * u] + d->biasprm[3 * u + 1] * length + d->biasprm[3 * u + 2] * velocity;
     if (m->actuator_forcelimited[u]) force = clampr(force, m->actuator_forcerange[2 * u], m->actuator_forcerange[2 * u + 1]);
     d->actuator_force[u] = force;
     d->qfrc_actuator[da] += gear * force;
@@ -1314,6 +1315,7 @@ typedef struct {
   float *info_go2;   /* Go2 joystick info block, GO2_INFO floats per env (layout: enum G2_*); NULL otherwise */
   float *first_qpos, *first_qvel, *first_ctrl, *first_warmstart, *first_time, *first_xpos, *first_site_xpos, *first_obs;
   float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;  /* NULL = model values */
+  float *dr_body_ipos, *dr_qpos0, *dr_dof_armature, *dr_gainprm, *dr_biasprm;      /* Go2 randomize.py leaves; NULL = model values */
   int *stats;   /* [n][4]: solver iterations, line-search iterations, ncon, overflow (last substep) */
 } obatch;
 
@@ -1327,6 +1329,13 @@ static void load_env(const omodel *m, const obatch *s, int e, odata *d) {
   for (int i = 0; i < m->nv; i++) {
     d->dof_damping[i] = s->dr_dof_damping ? s->dr_dof_damping[e * m->nv + i] : m->dof_damping[i];
     d->dof_frictionloss[i] = s->dr_dof_frictionloss ? s->dr_dof_frictionloss[e * m->nv + i] : m->dof_frictionloss[i];
+    d->dof_armature[i] = s->dr_dof_armature ? s->dr_dof_armature[e * m->nv + i] : m->dof_armature[i];
+  }
+  for (int i = 0; i < m->nbody * 3; i++) d->body_ipos[i] = s->dr_body_ipos ? s->dr_body_ipos[e * m->nbody * 3 + i] : m->body_ipos[i];
+  for (int i = 0; i < m->nq; i++) d->qpos0[i] = s->dr_qpos0 ? s->dr_qpos0[e * m->nq + i] : m->qpos0[i];
+  for (int i = 0; i < m->nu * 3; i++) {
+    d->gainprm[i] = s->dr_gainprm ? s->dr_gainprm[e * m->nu * 3 + i] : m->actuator_gainprm[i];
+    d->biasprm[i] = s->dr_biasprm ? s->dr_biasprm[e * m->nu * 3 + i] : m->actuator_biasprm[i];
   }
 }
 static void store_pipeline(const omodel *m, obatch *s, int e, const odata *d) {
@@ -2051,7 +2060,10 @@ int oracle_debug_forward(const omodel *m, const real *qpos, const real *qvel, co
   for (int i = 0; i < m->nu; i++) d->ctrl[i] = ctrl[i];
   for (int i = 0; i < m->ngeom * 3; i++) d->geom_friction[i] = m->geom_friction[i];
   for (int i = 0; i < m->nbody; i++) d->body_mass[i] = m->body_mass[i];
-  for (int i = 0; i < m->nv; i++) { d->dof_damping[i] = m->dof_damping[i]; d->dof_frictionloss[i] = m->dof_frictionloss[i]; }
+  for (int i = 0; i < m->nv; i++) { d->dof_damping[i] = m->dof_damping[i]; d->dof_frictionloss[i] = m->dof_frictionloss[i]; d->dof_armature[i] = m->dof_armature[i]; }
+  for (int i = 0; i < m->nbody * 3; i++) d->body_ipos[i] = m->body_ipos[i];
+  for (int i = 0; i < m->nq; i++) d->qpos0[i] = m->qpos0[i];
+  for (int i = 0; i < m->nu * 3; i++) { d->gainprm[i] = m->actuator_gainprm[i]; d->biasprm[i] = m->actuator_biasprm[i]; }
   d->time = 0;
   if (do_step) step_physics(m, d); else forward(m, d);
   return d->nefc;

@@ -30,9 +30,15 @@ class Dims(C.Structure):
 _lib = None
 
 # every symbol include/rsr_mjx.h declares
+# enum rsr_dr_field (include/rsr_mjx.h), in order
+DR_FIELDS = [
+    "geom_friction", "body_mass", "dof_damping", "dof_frictionloss",
+    "body_ipos", "qpos0", "dof_armature", "actuator_gainprm", "actuator_biasprm",
+]
+
 SYMBOLS = [
     "rsr_model_create", "rsr_model_dims", "rsr_model_destroy", "rsr_batch_create", "rsr_batch_destroy",
-    "rsr_batch_set_dr", "rsr_reset", "rsr_step", "rsr_view", "rsr_batch_set_debug",
+    "rsr_batch_set_dr", "rsr_batch_set_dr_field", "rsr_reset", "rsr_step", "rsr_view", "rsr_batch_set_debug",
     "rsr_timing_begin", "rsr_timing_end", "rsr_last_error",
 ]
 
@@ -56,6 +62,7 @@ def lib() -> C.CDLL:
     L.rsr_model_destroy.argtypes = [vp]
     L.rsr_model_destroy.restype = None
     L.rsr_batch_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.rsr_batch_set_dr_field.argtypes = [vp, i32, vp]
     L.rsr_batch_destroy.argtypes = [vp]
     L.rsr_batch_destroy.restype = None
     L.rsr_batch_set_dr.argtypes = [vp, vp, vp, vp, vp]

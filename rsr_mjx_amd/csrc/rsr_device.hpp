@@ -79,16 +79,19 @@ struct StepArgs {
   const float* action;          // [N][nu]         (step)
   const uint32_t* keys;         // [N][2]          (reset)
   const float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;   // [N][...] or null
+  // extended set (Go2 randomize.py:6-109; kernels built with Dims::DREX): [N][nbody*3], [N][nq], [N][nv], [N][nu*3], [N][nu*3]
+  const float *dr_body_ipos, *dr_qpos0, *dr_dof_armature, *dr_gainprm, *dr_biasprm;
   float* debug;                 // [N][RSR_DEBUG_FLOATS] or null
   int n;
 };
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false>
 struct Dims {
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
+  static constexpr bool DREX = DREX_;                // per-env body_ipos / qpos0 / armature / actuator gains staged in LDS
   // dofs [ISO0, ISO1) never share a constraint row or a kinematic chain with the others (the Airbot target body: it only
   // touches static geoms), so those entries of M, H and their Cholesky factors are structural zeros; checked on the host.
   static constexpr int ISO0 = ISO0_, ISO1 = ISO1_;
@@ -223,6 +226,9 @@ struct Smem {
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
   float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
+  // extended per-env overrides (Dims::DREX; one-element placeholders otherwise)
+  float dx_ipos[C::DREX ? C::NB * 3 : 1], dx_qpos0[C::DREX ? C::NQ : 1], dx_arma[C::DREX ? C::NV : 1];
+  float dx_gain[C::DREX ? C::NU * 3 : 1], dx_bias[C::DREX ? C::NU * 3 : 1];
   float xpos[C::NB * 3], xquat[C::NB * 4], spos[C::NS * 3];   // also read by the env epilogue
   float egeom[(C::NEG > 0 ? C::NEG : 1) * 3];          // world positions of the env's geoms of interest
   float smat[C::NS * 9], slinvel[C::NS * 3], sangvel[C::NS * 3];   // site frames / object velocities (sensor sources)
@@ -243,6 +249,13 @@ struct Smem {
   int clist[C::NCON + 4];
   union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
+
+// model fields that the extended domain randomisation makes per-env
+template <class C> __device__ __forceinline__ float mdl_qpos0(const DModel& m, const Smem<C>& s, int i) { if constexpr (C::DREX) return s.dx_qpos0[i]; else return m.qpos0[i]; }
+template <class C> __device__ __forceinline__ V3 mdl_ipos(const DModel& m, const Smem<C>& s, int b) { if constexpr (C::DREX) return ld3(&s.dx_ipos[3 * b]); else return ld3(&m.body_ipos[3 * b]); }
+template <class C> __device__ __forceinline__ float mdl_armature(const DModel& m, const Smem<C>& s, int i) { if constexpr (C::DREX) return s.dx_arma[i]; else return m.dof_armature[i]; }
+template <class C> __device__ __forceinline__ float mdl_gain(const DModel& m, const Smem<C>& s, int k) { if constexpr (C::DREX) return s.dx_gain[k]; else return m.actuator_gainprm[k]; }
+template <class C> __device__ __forceinline__ float mdl_bias(const DModel& m, const Smem<C>& s, int k) { if constexpr (C::DREX) return s.dx_bias[k]; else return m.actuator_biasprm[k]; }
 
 // =====================================================================================
 // stage 1: kinematics (MJX smooth.kinematics).  Lane b first builds body b's transform relative to its
@@ -270,7 +283,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
       st4(&s.qpos[qa + 3], lq);                    // MJX writes the normalised quaternion back
     } else {
       V3 jp = ld3(&m.body_jpos[3 * b]), jax = ld3(&m.body_jaxis[3 * b]);
-      float dq = s.qpos[qa] - m.qpos0[qa];
+      float dq = s.qpos[qa] - mdl_qpos0<C>(m, s, qa);
       if (jt == JNT_HINGE) {
         float sn, cs;
         sincosf(dq * 0.5f, &sn, &cs);
@@ -295,7 +308,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
     M33 R = q2m(q);
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.xmat[9 * b + c] = R.m[c];
-    st3(&s.x.a.xipos[3 * b], pos + mulv(R, ld3(&m.body_ipos[3 * b])));
+    st3(&s.x.a.xipos[3 * b], pos + mulv(R, mdl_ipos<C>(m, s, b)));
     M33 Ri = q2m(qmul(q, ld4(&m.body_iquat[4 * b])));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.ximat[9 * b + c] = Ri.m[c];
@@ -407,7 +420,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
       int j = __builtin_ctz(mask); mask &= mask - 1;
       const float* cj = &s.cdof[6 * j];
       float v = f[0] * cj[0] + f[1] * cj[1] + f[2] * cj[2] + f[3] * cj[3] + f[4] * cj[4] + f[5] * cj[5];
-      if (j == i) v += m.dof_armature[i];
+      if (j == i) v += mdl_armature<C>(m, s, i);
       s.M[i * C::LD + j] = v;
       s.M[j * C::LD + i] = v;
     }
@@ -853,8 +866,8 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
       float length = s.qpos[m.jnt_qposadr[m.dof_jntid[i]]] * gear, velocity = qvel_i * gear;
       float ctrl = s.ctrl[u];
       if (m.actuator_ctrllimited[u]) ctrl = clampf(ctrl, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
-      float force = m.actuator_gainprm[3 * u] * ctrl + m.actuator_biasprm[3 * u] + m.actuator_biasprm[3 * u + 1] * length +
-                    m.actuator_biasprm[3 * u + 2] * velocity;
+      float force = mdl_gain<C>(m, s, 3 * u) * ctrl + mdl_bias<C>(m, s, 3 * u) + mdl_bias<C>(m, s, 3 * u + 1) * length +
+                    mdl_bias<C>(m, s, 3 * u + 2) * velocity;
       if (m.actuator_forcelimited[u]) force = clampf(force, m.actuator_forcerange[2 * u], m.actuator_forcerange[2 * u + 1]);
       s.aforce[u] = force;
       act = gear * force;
@@ -926,7 +939,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   WSYNC();
   if (lane < C::NEQ && m.eq_active0[lane]) {
     int e = lane, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
-    float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
+    float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j2]) : 0.0f;
     const float* dt = &m.eq_data[5 * e];
     float deriv = dt[1] + dif * (2.0f * dt[2] + dif * (3.0f * dt[3] + dif * 4.0f * dt[4]));
     if (j2 >= 0) s.x.b.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
@@ -974,10 +987,10 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
       o.bn = r; o.bk = r;
       if (r < r_fric) {
         int e = r, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
-        float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - m.qpos0[m.jnt_qposadr[j2]] : 0.0f;
+        float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j2]) : 0.0f;
         const float* dt = &m.eq_data[5 * e];
         float poly = dt[0] + dif * (dt[1] + dif * (dt[2] + dif * (dt[3] + dif * dt[4])));
-        pos = s.qpos[m.jnt_qposadr[j1]] - m.qpos0[m.jnt_qposadr[j1]] - poly;
+        pos = s.qpos[m.jnt_qposadr[j1]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j1]) - poly;
         invw = m.dof_invweight0[m.jnt_dofadr[j1]] + (j2 >= 0 ? m.dof_invweight0[m.jnt_dofadr[j2]] : 0.0f);
         sr0 = m.eq_solref[2 * e]; sr1 = m.eq_solref[2 * e + 1]; si = &m.eq_solimp[5 * e];
       } else if (r < r_lim) {

@@ -20,7 +20,7 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
-                     /*NINFO*/ 144>;
+                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
@@ -69,6 +69,15 @@ __device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, i
   if (lane < C::NV) {
     s.damp[lane] = a.dr_dof_damping ? a.dr_dof_damping[(size_t)e * C::NV + lane] : m.dof_damping[lane];
     s.floss[lane] = a.dr_dof_frictionloss ? a.dr_dof_frictionloss[(size_t)e * C::NV + lane] : m.dof_frictionloss[lane];
+  }
+  if constexpr (C::DREX) {
+    if (lane < C::NB * 3) s.dx_ipos[lane] = a.dr_body_ipos ? a.dr_body_ipos[(size_t)e * C::NB * 3 + lane] : m.body_ipos[lane];
+    if (lane < C::NQ) s.dx_qpos0[lane] = a.dr_qpos0 ? a.dr_qpos0[(size_t)e * C::NQ + lane] : m.qpos0[lane];
+    if (lane < C::NV) s.dx_arma[lane] = a.dr_dof_armature ? a.dr_dof_armature[(size_t)e * C::NV + lane] : m.dof_armature[lane];
+    if (lane < C::NU * 3) {
+      s.dx_gain[lane] = a.dr_gainprm ? a.dr_gainprm[(size_t)e * C::NU * 3 + lane] : m.actuator_gainprm[lane];
+      s.dx_bias[lane] = a.dr_biasprm ? a.dr_biasprm[(size_t)e * C::NU * 3 + lane] : m.actuator_biasprm[lane];
+    }
   }
 }
 
@@ -865,6 +874,7 @@ struct rsr_batch {
   DModel dm;            // host copy of the device model view
   DModel* dmodel;       // the same struct in device memory (kernels take a pointer: fewer live SGPRs)
   const float *dr_fric, *dr_mass, *dr_damp, *dr_floss;
+  const float* dr_ex[5];    // body_ipos, qpos0, dof_armature, actuator_gainprm, actuator_biasprm
   float* debug;
   hipEvent_t ev0, ev1; bool timing; int launches;
 };
@@ -1014,6 +1024,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   rsr_batch* b = new rsr_batch();
   b->model = m; b->n = num_envs; b->device = hip_device;
   b->dr_fric = b->dr_mass = b->dr_damp = b->dr_floss = nullptr; b->debug = nullptr;
+  for (auto& p : b->dr_ex) p = nullptr;
   b->timing = false; b->launches = 0; b->ev0 = b->ev1 = nullptr;
   b->state = state; b->owns_state = false; b->dblob = nullptr;
   if (!state) {
@@ -1051,6 +1062,22 @@ extern "C" int rsr_batch_set_dr(rsr_batch* b, const float* geom_friction, const 
   return RSR_OK;
 }
 
+extern "C" int rsr_batch_set_dr_field(rsr_batch* b, int dr_field, const float* dev_values) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_dr_field: null batch");
+  switch (dr_field) {
+    case RSR_DR_GEOM_FRICTION: b->dr_fric = dev_values; return RSR_OK;
+    case RSR_DR_BODY_MASS: b->dr_mass = dev_values; return RSR_OK;
+    case RSR_DR_DOF_DAMPING: b->dr_damp = dev_values; return RSR_OK;
+    case RSR_DR_DOF_FRICTIONLOSS: b->dr_floss = dev_values; return RSR_OK;
+    case RSR_DR_BODY_IPOS: case RSR_DR_QPOS0: case RSR_DR_DOF_ARMATURE: case RSR_DR_ACTUATOR_GAINPRM: case RSR_DR_ACTUATOR_BIASPRM:
+      if (b->model->dims.env_kind != rsr::ENV_GO2)
+        return fail(RSR_ERR_UNSUPPORTED, "rsr_batch_set_dr_field: this field is per-env only in the Go2 kernels (randomize.py); the Airbot kernels take the four fields of rsr_batch_set_dr");
+      b->dr_ex[dr_field - RSR_DR_BODY_IPOS] = dev_values;
+      return RSR_OK;
+    default: return fail(RSR_ERR_ARG, "rsr_batch_set_dr_field: unknown field");
+  }
+}
+
 extern "C" int rsr_batch_set_debug(rsr_batch* b, float* dev_buffer) {
   if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_debug: null batch");
   b->debug = dev_buffer;
@@ -1061,6 +1088,7 @@ static rsr::StepArgs make_args(rsr_batch* b) {
   rsr::StepArgs a{};
   a.state = b->state; a.n = b->n;
   a.dr_geom_friction = b->dr_fric; a.dr_body_mass = b->dr_mass; a.dr_dof_damping = b->dr_damp; a.dr_dof_frictionloss = b->dr_floss;
+  a.dr_body_ipos = b->dr_ex[0]; a.dr_qpos0 = b->dr_ex[1]; a.dr_dof_armature = b->dr_ex[2]; a.dr_gainprm = b->dr_ex[3]; a.dr_biasprm = b->dr_ex[4];
   a.debug = b->debug;
   return a;
 }

@@ -174,7 +174,7 @@ class BatchedEnv:
             off = (ptr.value - self.record.data_ptr()) // 4
             v = self.record[:, off:off + shape[1]]
             self._views[name] = v.view(torch.int32) if name == "stats" else v
-        self._dr = None
+        self._dr = {}
         self._debug = None
         if randomization is not None:
             self.set_randomization(randomization)
@@ -211,21 +211,25 @@ class BatchedEnv:
         return self._views[name]
 
     def set_randomization(self, dr: Dict[str, Any]) -> None:
-        """Per-env model overrides: geom_friction [N,ngeom,3], body_mass [N,nbody], dof_damping [N,nv],
-        dof_frictionloss [N,nv] (numpy or torch)."""
+        """Per-env model leaves (numpy or torch, leading dim N): geom_friction [N,ngeom,3], body_mass [N,nbody],
+        dof_damping [N,nv], dof_frictionloss [N,nv]; the Go2 kernels also take body_ipos [N,nbody,3], qpos0 [N,nq],
+        dof_armature [N,nv], actuator_gainprm / actuator_biasprm [N,nu,3] (go2/randomize.py:6-109).  Missing or None
+        keys restore the model's value."""
         import torch
+        unknown = set(dr) - set(_lib.DR_FIELDS)
+        if unknown:
+            raise KeyError(f"not a randomisable model field: {sorted(unknown)}")
         keep = {}
-        for k in ("geom_friction", "body_mass", "dof_damping", "dof_frictionloss"):
+        for fid, k in enumerate(_lib.DR_FIELDS):
             v = dr.get(k)
             if v is None:
-                keep[k] = None
+                if self._dr.get(k) is not None:
+                    _lib.check(_lib.lib().rsr_batch_set_dr_field(self._batch, fid, None))
                 continue
             t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, dtype=torch.float32).to(self.device)
             keep[k] = t.reshape(self.num_envs, -1).contiguous()
+            _lib.check(_lib.lib().rsr_batch_set_dr_field(self._batch, fid, C.c_void_p(keep[k].data_ptr())))
         self._dr = keep
-        p = lambda k: C.c_void_p(keep[k].data_ptr()) if keep[k] is not None else None
-        _lib.check(_lib.lib().rsr_batch_set_dr(self._batch, p("geom_friction"), p("body_mass"), p("dof_damping"),
-                                               p("dof_frictionloss")))
 
     def enable_debug(self, on: bool = True):
         import torch

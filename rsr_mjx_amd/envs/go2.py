@@ -12,6 +12,10 @@ from __future__ import annotations
 import os
 from typing import Any, Dict, Optional
 
+import numpy as np
+
+from .. import prng
+
 from ..mjcf import CompiledModel, compile_mjcf
 from . import config as cfg
 from .airbot import BatchedEnv, State, _ASSETS
@@ -119,9 +123,55 @@ def wrap_for_brax_training(env: Joystick, num_envs: int, episode_length: int = 1
     """Counterpart of reference _src/wrapper.py:41-74 (Vmap -> Episode -> AutoReset), fused into the step kernel."""
     if action_repeat != 1:
         raise NotImplementedError("action_repeat != 1")
+    benv = env.batched(num_envs, episode_length=episode_length, auto_reset=True)
     if randomization_fn is not None:
-        raise NotImplementedError("Go2 domain randomisation (go2/randomize.py) is not built yet")
-    return env.batched(num_envs, episode_length=episode_length, auto_reset=True)
+        benv.set_randomization(randomization_fn(env.sys))     # the per-env leaves of MjxDomainRandomizationVmapWrapper (wrapper.py:107-138)
+    return benv
+
+
+FLOOR_GEOM_ID = 0
+TORSO_BODY_ID = 1
+
+
+def domain_randomize(sys, rng: np.ndarray) -> Dict[str, np.ndarray]:
+    """Counterpart of reference _src/locomotion/go2/randomize.py:6-109: per env, floor friction U(0.4, 1), leg
+    frictionloss x U(0.9, 1.1), leg armature x U(1, 1.05), kp x U(0.95, 1.05) (gainprm[:, 0] and biasprm[:, 1]), kd (leg
+    dof_damping) x U(0.95, 1.05), torso com + U(-0.2, 0.2)^3, link masses x U(0.9, 1.1), torso mass + U(-3, 3), and
+    qpos0[7:] + U(-0.05, 0.05).  rng: uint32 [N, 2] (one key per env).  Returns the nine per-env model leaves keyed by
+    field name (actuator_gainprm / actuator_biasprm in this build's 3-column form)."""
+    rng = np.asarray(rng, dtype=np.uint32).reshape(-1, 2)
+    n = rng.shape[0]
+    A = sys.arrays
+    f32 = lambda k: np.tile(A[k].astype(np.float32)[None], (n,) + (1,) * A[k].ndim)
+
+    def draw(shape, lo, hi):
+        nonlocal rng
+        ks = prng.split(rng, 2)                 # rng, key = jax.random.split(rng)
+        rng, key = ks[:, 0], ks[:, 1]
+        return prng.uniform(key, shape, lo, hi).astype(np.float32)
+
+    fr = f32("geom_friction")
+    fr[:, FLOOR_GEOM_ID, 0] = draw((), 0.4, 1.0)
+    floss = f32("dof_frictionloss")
+    floss[:, 6:] = floss[:, 6:] * draw((12,), 0.9, 1.1)
+    arma = f32("dof_armature")
+    arma[:, 6:] = arma[:, 6:] * draw((12,), 1.0, 1.05)
+    kp = draw((12,), 0.95, 1.05)
+    gain, bias = f32("actuator_gainprm"), f32("actuator_biasprm")
+    gain[:, :, 0] = gain[:, :, 0] * kp
+    bias[:, :, 1] = bias[:, :, 1] * kp
+    damp = f32("dof_damping")
+    damp[:, 6:] = damp[:, 6:] * draw((12,), 0.95, 1.05)
+    dpos_x = draw((), -0.2, 0.2)
+    dpos_yz = draw((2,), -0.2, 0.2)
+    ipos = f32("body_ipos")
+    ipos[:, TORSO_BODY_ID] = ipos[:, TORSO_BODY_ID] + np.concatenate([dpos_x[:, None], dpos_yz], axis=1)
+    mass = f32("body_mass") * draw((sys.nbody,), 0.9, 1.1)
+    mass[:, TORSO_BODY_ID] = mass[:, TORSO_BODY_ID] + draw((), -3.0, 3.0)
+    qpos0 = f32("qpos0")
+    qpos0[:, 7:] = qpos0[:, 7:] + draw((12,), -0.05, 0.05)
+    return dict(geom_friction=fr, body_ipos=ipos, body_mass=mass, qpos0=qpos0, dof_frictionloss=floss,
+                dof_armature=arma, actuator_gainprm=gain, actuator_biasprm=bias, dof_damping=damp)
 
 
 _ENVS = {"Go2JoystickFlatTerrain": dict(task="flat_terrain")}      # _src/locomotion/__init__.py:16-26

@@ -164,19 +164,73 @@ def test_go2_step_bookkeeping_and_state_rewards(go2_model, oracle_mod):
     assert np.median(st["qpos"][:, 2]) > 0.2 and np.isfinite(st["obs"]).all()      # most robots still stand under random actions
 
 
+def test_go2_domain_randomize(go2_model, oracle_mod):
+    """go2/randomize.py:6-109: ranges, which entries move, key chaining, and that every leaf reaches the physics."""
+    from rsr_mjx_amd.envs import go2
+    n = 64
+    A = go2_model.arrays
+    dr = go2.domain_randomize(go2_model, prng.split(prng.PRNGKey(5), n))
+    assert set(dr) == {"geom_friction", "body_ipos", "body_mass", "qpos0", "dof_frictionloss", "dof_armature",
+                       "actuator_gainprm", "actuator_biasprm", "dof_damping"}
+    fr = dr["geom_friction"]
+    assert ((fr[:, 0, 0] >= 0.4) & (fr[:, 0, 0] < 1.0)).all() and np.array_equal(fr[:, 1:], np.tile(A["geom_friction"][None, 1:], (n, 1, 1)).astype(f32))
+    np.testing.assert_array_equal(fr[:, 0, 1:], np.tile(A["geom_friction"][0, 1:].astype(f32), (n, 1)))
+    for k, lo, hi in (("dof_frictionloss", 0.9, 1.1), ("dof_armature", 1.0, 1.05), ("dof_damping", 0.95, 1.05)):
+        base = A[k].astype(f32)
+        np.testing.assert_array_equal(dr[k][:, :6], np.tile(base[:6], (n, 1)))
+        r = dr[k][:, 6:] / base[6:]
+        assert (r >= lo - 1e-6).all() and (r <= hi + 1e-6).all() and r.std() > 0.2 * (hi - lo) / 3.5, k
+    kp = dr["actuator_gainprm"][:, :, 0] / A["actuator_gainprm"][:, 0].astype(f32)
+    np.testing.assert_allclose(dr["actuator_biasprm"][:, :, 1] / A["actuator_biasprm"][:, 1].astype(f32), kp, rtol=1e-6)
+    assert (kp >= 0.95 - 1e-6).all() and (kp <= 1.05 + 1e-6).all()
+    np.testing.assert_array_equal(dr["actuator_biasprm"][:, :, 2], np.tile(A["actuator_biasprm"][:, 2].astype(f32), (n, 1)))
+    dp = dr["body_ipos"] - A["body_ipos"].astype(f32)
+    assert (np.abs(dp[:, 1]) <= 0.2 + 1e-6).all() and np.abs(dp[:, 1]).max() > 0.1 and not dp[:, 2:].any() and not dp[:, 0].any()
+    m0 = A["body_mass"].astype(f32)
+    rm = dr["body_mass"][:, 2:] / m0[2:]
+    assert (rm >= 0.9 - 1e-6).all() and (rm <= 1.1 + 1e-6).all()
+    dt = dr["body_mass"][:, 1] - m0[1]
+    assert (dt > -3.0 - 0.1 * m0[1] - 1e-4).all() and (dt < 3.0 + 0.1 * m0[1] + 1e-4).all() and dt.std() > 1.0
+    dq = dr["qpos0"] - A["qpos0"].astype(f32)
+    assert not dq[:, :7].any() and (np.abs(dq[:, 7:]) <= 0.05 + 1e-6).all() and np.abs(dq[:, 7:]).max() > 0.04
+    # the first draw uses key = split(rng)[1] of the env's key, as `rng, key = jax.random.split(rng)` does
+    k0 = prng.split(prng.PRNGKey(5), n)
+    np.testing.assert_array_equal(fr[:, 0, 0], prng.uniform(prng.split(k0, 2)[:, 1], (), 0.4, 1.0).astype(f32))
+    # every leaf reaches the oracle's physics: one leaf at a time changes the step
+    blob = make_go2_blob(go2_model)
+    orc = oracle_mod.Oracle(blob)
+    keys = prng.split(prng.PRNGKey(6), n)
+    act = np.clip(np.random.default_rng(0).normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
+    def run(d):
+        st = orc.new_state(n, d)
+        orc.reset(st, keys)
+        for _ in range(3):
+            orc.step(st, act)
+        return st["qvel"].copy()
+    base = run(None)
+    alias = {"actuator_gainprm": "gainprm", "actuator_biasprm": "biasprm"}
+    for k in dr:
+        one = {alias.get(k, k): dr[k]}
+        assert np.abs(run(one) - base).max() > 1e-6, k
+
+
 @pytest.mark.gpu
-def test_go2_hip_parity(go2_model, oracle_mod):
+@pytest.mark.parametrize("randomize", [False, True])
+def test_go2_hip_parity(go2_model, oracle_mod, randomize):
     """BASELINE configs[3] family (Go2JoystickFlatTerrain): reset bit-exact in the PRNG-only parts, teacher-forced steps.
     The Go2 solve is intentionally unconverged (iterations=1, ls_iterations=5), so velocities carry the usual fp32 noise."""
     import torch
     from rsr_mjx_amd.envs import go2
     n = 512
-    env = go2.load("Go2JoystickFlatTerrain").batched(n, episode_length=1000, auto_reset=True)
+    jenv = go2.load("Go2JoystickFlatTerrain")
+    dr = go2.domain_randomize(jenv.sys, prng.split(prng.PRNGKey(12), n)) if randomize else None
+    env = go2.wrap_for_brax_training(jenv, n, episode_length=1000, randomization_fn=(lambda sys: dr) if randomize else None)
     assert env.observation_size == 48 and env.action_size == 12 and abs(env.dt - 0.02) < 1e-12
     orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
     o64 = oracle_mod.Oracle(env.blob, "f64"); o64.set_ncon_cap(env.dims.ncon_max)
     keys = prng.split(prng.PRNGKey(11), n)
-    st = orc.new_state(n)
+    odr = None if dr is None else {{"actuator_gainprm": "gainprm", "actuator_biasprm": "biasprm"}.get(k, k): v for k, v in dr.items()}
+    st = orc.new_state(n, odr)
     orc.reset(st, keys)
     state = env.reset(keys)
     torch.cuda.synchronize()
