@@ -61,8 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--no-dr", action="store_true", help="disable domain randomisation")
-    ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2"],
-                    help="cube = BASELINE headline (configs[1] family); tshape / go2 = configs[2] / configs[3] families")
+    ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2", "go2rough"],
+                    help="cube = BASELINE headline (configs[1] family); tshape / go2 / go2rough = configs[2] / [3] / [4] families")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,10 +89,11 @@ def main():
     key_env = prng.split(prng.PRNGKey(0), 3)[1]
     lo, hi = shard_range(total, rank, world)
     keys = shard_keys(key_env, total, rank, world)
-    if args.workload == "go2":
+    if args.workload in ("go2", "go2rough"):
         from rsr_mjx_amd.envs import go2
-        envdef = go2.load("Go2JoystickFlatTerrain", device=f"cuda:{local_rank}")
-        dr, ep_len, act_std, wl_name = None, 1000, 0.3, "Go2JoystickFlatTerrain"
+        wl_name = "Go2JoystickFlatTerrain" if args.workload == "go2" else "Go2JoystickRoughTerrain"
+        envdef = go2.load(wl_name, device=f"cuda:{local_rank}")
+        dr, ep_len, act_std = None, 1000, 0.3
         args.no_dr = True
     elif args.workload == "tshape":
         from rsr_mjx_amd.envs.airbot import AirbotTShape
@@ -140,7 +141,7 @@ def main():
     env_steps = float(metrics_all[:, 0].sum().item())
 
     if rank == 0:
-        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2044}[args.workload]
+        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2044, "go2rough": 2044}[args.workload]
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()

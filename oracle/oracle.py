@@ -60,6 +60,7 @@ def _load(precision: str) -> C.CDLL:
     lib.oracle_uniform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.oracle_box_box.argtypes = [C.c_void_p] * 8
     lib.oracle_plane_box.argtypes = [C.c_void_p] * 7
+    lib.oracle_hfield_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 

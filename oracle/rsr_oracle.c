@@ -91,6 +91,8 @@ typedef struct {
   const int *pair_geom1, *pair_geom2, *pair_kind, *pair_condim;
   const float *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
   const float *qpos0;
+  const float *hfield_size, *hfield_data;   /* one height field at most: size (x, y, z, base), data [nrow*ncol] in [0, 1] */
+  const int *hfield_nrow, *hfield_ncol;
   real timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
   /* env */
@@ -130,7 +132,7 @@ omodel *oracle_model_create(const void *blob, int nbytes) {
   F(actuator_gear); F(actuator_gainprm); F(actuator_biasprm); F(actuator_ctrlrange); F(actuator_forcerange);
   I(pair_geom1); I(pair_geom2); I(pair_kind); I(pair_condim);
   F(pair_solref); F(pair_solimp); F(pair_margin); F(pair_gap);
-  F(qpos0);
+  F(qpos0); F(hfield_size); F(hfield_data); I(hfield_nrow); I(hfield_ncol);
   m->timestep = ((const float *)blob_find(b, "opt_timestep", NULL))[0];
   for (int i = 0; i < 3; i++) m->gravity[i] = ((const float *)blob_find(b, "opt_gravity", NULL))[i];
   m->tolerance = ((const float *)blob_find(b, "opt_tolerance", NULL))[0];
@@ -599,6 +601,98 @@ static int plane_sphere(const real *ppos, const real *pmat, const real *spos, re
   return 1;
 }
 
+/* closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5: Voronoi regions of the
+ * vertices, edges and face) */
+static void closest_on_triangle(const real *p, const real *a, const real *b, const real *c, real *q) {
+  real ab[3], ac[3], ap[3], bp[3], cp[3];
+  for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; bp[k] = p[k] - b[k]; cp[k] = p[k] - c[k]; }
+  real d1 = v3dot(ab, ap), d2 = v3dot(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { v3copy(q, a); return; }
+  real d3 = v3dot(ab, bp), d4 = v3dot(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { v3copy(q, b); return; }
+  real vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { real v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) q[k] = a[k] + v * ab[k]; return; }
+  real d5 = v3dot(ab, cp), d6 = v3dot(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { v3copy(q, c); return; }
+  real vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { real w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) q[k] = a[k] + w * ac[k]; return; }
+  real va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+    real w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int k = 0; k < 3; k++) q[k] = b[k] + w * (c[k] - b[k]);
+    return;
+  }
+  real den = (real)1 / (va + vb + vc), v = vb * den, w = vc * den;
+  for (int k = 0; k < 3; k++) q[k] = a[k] + ab[k] * v + ac[k] * w;
+}
+
+/* sphere (geom2) vs height field (geom1): ONE contact at the point of the triangulated surface closest to the
+ * sphere centre.  Cells are split along the diagonal (col, row) - (col+1, row+1); elevation = data * size[2].
+ * MJX 3.2.4 collides the sphere with the triangular prisms of a sub-grid and keeps the deepest contact; its
+ * source is not available here, so this follows the geometry (closest surface point; centre below the surface:
+ * perpendicular depth to the triangle above it), not MJX's enumeration -- "parity unpinned", see DESIGN.md.
+ * The sphere must not span more than two grid lines per axis (checked at model creation). */
+static int hfield_sphere(const real *hpos, const real *hmat, const float *hsize, int nrow, int ncol, const float *data,
+                         const real *spos, real radius, cpoint *out, real *normal) {
+  real rel[3] = {spos[0] - hpos[0], spos[1] - hpos[1], spos[2] - hpos[2]}, p[3];
+  for (int c = 0; c < 3; c++) p[c] = hmat[c] * rel[0] + hmat[3 + c] * rel[1] + hmat[6 + c] * rel[2];
+  real sx = hsize[0], sy = hsize[1], sz = hsize[2];
+  if (p[0] < -sx || p[0] > sx || p[1] < -sy || p[1] > sy) return 0;
+  real dx = (real)2 * sx / (real)(ncol - 1), dy = (real)2 * sy / (real)(nrow - 1);
+#define HZ(r_, c_) ((real)data[(r_) * ncol + (c_)] * sz)
+  /* the triangle above/below the centre */
+  int ci = (int)floor((double)((p[0] + sx) / dx)), ri = (int)floor((double)((p[1] + sy) / dy));
+  ci = ci < 0 ? 0 : (ci > ncol - 2 ? ncol - 2 : ci); ri = ri < 0 ? 0 : (ri > nrow - 2 ? nrow - 2 : ri);
+  real n[3], q[3], dist;
+  {
+    real x0 = -sx + dx * (real)ci, y0 = -sy + dy * (real)ri;
+    real u = (p[0] - x0) / dx, v = (p[1] - y0) / dy;
+    real z00 = HZ(ri, ci), z10 = HZ(ri, ci + 1), z01 = HZ(ri + 1, ci), z11 = HZ(ri + 1, ci + 1);
+    real gx, gy, zs;     /* surface gradient and height under the centre */
+    if (u >= v) { gx = (z10 - z00) / dx; gy = (z11 - z10) / dy; zs = z00 + (z10 - z00) * u + (z11 - z10) * v; }
+    else { gx = (z11 - z01) / dx; gy = (z01 - z00) / dy; zs = z00 + (z11 - z01) * u + (z01 - z00) * v; }
+    if (p[2] < zs) {
+      real inv = (real)1 / rsqrt_(gx * gx + gy * gy + (real)1);
+      n[0] = -gx * inv; n[1] = -gy * inv; n[2] = inv;
+      real depth = (zs - p[2]) * inv;
+      dist = -depth - radius;
+      for (int k = 0; k < 3; k++) q[k] = p[k] + n[k] * depth;
+      goto emit;
+    }
+  }
+  {
+    int c0 = (int)floor((double)((p[0] - radius + sx) / dx)), r0 = (int)floor((double)((p[1] - radius + sy) / dy));
+    c0 = c0 < 0 ? 0 : (c0 > ncol - 3 ? ncol - 3 : c0); r0 = r0 < 0 ? 0 : (r0 > nrow - 3 ? nrow - 3 : r0);
+    real best = (real)1e30;
+    for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) {
+      int cc = c0 + i, rr = r0 + j;
+      real x0 = -sx + dx * (real)cc, y0 = -sy + dy * (real)rr, x1 = x0 + dx, y1 = y0 + dy;
+      real v00[3] = {x0, y0, HZ(rr, cc)}, v10[3] = {x1, y0, HZ(rr, cc + 1)}, v01[3] = {x0, y1, HZ(rr + 1, cc)}, v11[3] = {x1, y1, HZ(rr + 1, cc + 1)};
+      for (int t = 0; t < 2; t++) {
+        real qq[3];
+        if (t == 0) closest_on_triangle(p, v00, v10, v11, qq); else closest_on_triangle(p, v00, v11, v01, qq);
+        real d[3] = {p[0] - qq[0], p[1] - qq[1], p[2] - qq[2]};
+        real d2 = v3dot(d, d);
+        if (d2 < best) { best = d2; v3copy(q, qq); }
+      }
+    }
+    real dn = rsqrt_(best);
+    if (dn < (real)1e-12) { n[0] = 0; n[1] = 0; n[2] = 1; }
+    else for (int k = 0; k < 3; k++) n[k] = (p[k] - q[k]) / dn;
+    dist = dn - radius;
+  }
+emit:
+#undef HZ
+  out[0].dist = dist;
+  real pl[3];
+  for (int k = 0; k < 3; k++) pl[k] = q[k] + n[k] * ((real)0.5 * dist);
+  for (int c = 0; c < 3; c++) {
+    normal[c] = hmat[3 * c] * n[0] + hmat[3 * c + 1] * n[1] + hmat[3 * c + 2] * n[2];
+    out[0].pos[c] = hpos[c] + hmat[3 * c] * pl[0] + hmat[3 * c + 1] * pl[1] + hmat[3 * c + 2] * pl[2];
+  }
+  return 1;
+}
+
 /* box-box: 15-axis SAT, reference-face clipping (Sutherland-Hodgman against the reference rectangle),
  * <=4 manifold points; edge-edge gives one point.  Only penetrating configurations produce contacts
  * (separated pairs contribute nothing to the solve).
@@ -770,6 +864,10 @@ static void collision(const omodel *m, odata *d) {
         break;
       case PAIR_PLANE_SPHERE:
         n = plane_sphere(&d->geom_xpos[3 * g1], &d->geom_xmat[9 * g1], &d->geom_xpos[3 * g2], s2[0], pts, normal);
+        break;
+      case PAIR_HFIELD_SPHERE:
+        n = hfield_sphere(&d->geom_xpos[3 * g1], &d->geom_xmat[9 * g1], m->hfield_size, m->hfield_nrow[0], m->hfield_ncol[0], m->hfield_data,
+                          &d->geom_xpos[3 * g2], s2[0], pts, normal);
         break;
       default: n = 0;
     }
@@ -2119,6 +2217,13 @@ int oracle_box_box(const real *pa, const real *Ra, const real *sa, const real *p
 int oracle_plane_box(const real *pp, const real *pm, const real *bp, const real *bm, const real *size, real *out, real *normal) {
   cpoint pts[4];
   int n = plane_box(pp, pm, bp, bm, size, pts, normal);
+  for (int i = 0; i < n; i++) { out[4 * i] = pts[i].dist; for (int c = 0; c < 3; c++) out[4 * i + 1 + c] = pts[i].pos[c]; }
+  return n;
+}
+int oracle_hfield_sphere(const real *hp, const real *hm, const float *hsize, int nrow, int ncol, const float *data, const real *sp,
+                         const real *radius, real *out, real *normal) {
+  cpoint pts[1];
+  int n = hfield_sphere(hp, hm, hsize, nrow, ncol, data, sp, radius[0], pts, normal);
   for (int i = 0; i < n; i++) { out[4 * i] = pts[i].dist; for (int c = 0; c < 3; c++) out[4 * i + 1 + c] = pts[i].pos[c]; }
   return n;
 }

@@ -50,6 +50,9 @@ struct DModel {
   const int *pair_b1, *pair_b2, *pair_root1, *pair_root2, *dof_rootid, *dof_jtype, *dof_k, *dof_act, *dof_afl, *body_jtype, *body_qposadr;
   const unsigned *pair_mask1, *pair_mask2;
   const float *pair_tw, *pair_incl, *dof_afrange, *body_jpos, *body_jaxis;
+  // height field (at most one): size = (x, y, z, base) half extents / elevation scale, data [nrow*ncol] in [0, 1]
+  const float *hfield_size, *hfield_data;
+  const int *hfield_nrow, *hfield_ncol;
   const float *qpos0;
   const int *env_ids;
   const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
@@ -87,10 +90,11 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false>
 struct Dims {
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
+  static constexpr bool HFIELD = HFIELD_;            // sphere / height-field pairs are compiled in
   static constexpr bool DREX = DREX_;                // per-env body_ipos / qpos0 / armature / actuator gains staged in LDS
   // dofs [ISO0, ISO1) never share a constraint row or a kinematic chain with the others (the Airbot target body: it only
   // touches static geoms), so those entries of M, H and their Cholesky factors are structural zeros; checked on the host.
@@ -727,6 +731,83 @@ __device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
   }
 }
 
+// closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5)
+__device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
+  V3 ab = b - a, ac = c - a, ap = p - a;
+  float d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) return a;
+  V3 bp = p - b;
+  float d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) return b;
+  float vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 / (d1 - d3));
+  V3 cp = p - c;
+  float d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) return c;
+  float vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 / (d2 - d6));
+  float va = d3 * d6 - d5 * d4;
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)));
+  float den = 1.0f / (va + vb + vc);
+  return a + ab * (vb * den) + ac * (vc * den);
+}
+
+// sphere (geom2) vs height field (geom1): one contact at the closest point of the triangulated surface
+// (cells split along (col,row)-(col+1,row+1)); centre below the surface: perpendicular depth to the triangle above it.
+// Same construction as the oracle's hfield_sphere; the sphere spans at most two grid lines per axis (host check).
+__device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const float* hmat, V3 spos, float radius, float& dist, V3& pos, V3& nrm) {
+  const int nrow = m.hfield_nrow[0], ncol = m.hfield_ncol[0];
+  const float sx = m.hfield_size[0], sy = m.hfield_size[1], sz = m.hfield_size[2];
+  const float* __restrict__ data = m.hfield_data;
+  V3 rel = spos - hpos;
+  V3 p = v3(hmat[0] * rel.x + hmat[3] * rel.y + hmat[6] * rel.z, hmat[1] * rel.x + hmat[4] * rel.y + hmat[7] * rel.z,
+            hmat[2] * rel.x + hmat[5] * rel.y + hmat[8] * rel.z);
+  if (p.x < -sx || p.x > sx || p.y < -sy || p.y > sy) return false;
+  const float dx = 2.0f * sx / (float)(ncol - 1), dy = 2.0f * sy / (float)(nrow - 1);
+  int ci = (int)floorf((p.x + sx) / dx), ri = (int)floorf((p.y + sy) / dy);
+  ci = ci < 0 ? 0 : (ci > ncol - 2 ? ncol - 2 : ci); ri = ri < 0 ? 0 : (ri > nrow - 2 ? nrow - 2 : ri);
+  V3 n, q;
+  float x0 = -sx + dx * (float)ci, y0 = -sy + dy * (float)ri;
+  float u = (p.x - x0) / dx, v = (p.y - y0) / dy;
+  float z00 = data[ri * ncol + ci] * sz, z10 = data[ri * ncol + ci + 1] * sz, z01 = data[(ri + 1) * ncol + ci] * sz, z11 = data[(ri + 1) * ncol + ci + 1] * sz;
+  float gx, gy, zs;
+  if (u >= v) { gx = (z10 - z00) / dx; gy = (z11 - z10) / dy; zs = z00 + (z10 - z00) * u + (z11 - z10) * v; }
+  else { gx = (z11 - z01) / dx; gy = (z01 - z00) / dy; zs = z00 + (z11 - z01) * u + (z01 - z00) * v; }
+  if (p.z < zs) {
+    float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
+    n = v3(-gx * inv, -gy * inv, inv);
+    float depth = (zs - p.z) * inv;
+    dist = -depth - radius;
+    q = p + n * depth;
+  } else {
+    int c0 = (int)floorf((p.x - radius + sx) / dx), r0 = (int)floorf((p.y - radius + sy) / dy);
+    c0 = c0 < 0 ? 0 : (c0 > ncol - 3 ? ncol - 3 : c0); r0 = r0 < 0 ? 0 : (r0 > nrow - 3 ? nrow - 3 : r0);
+    float best = 1e30f;
+    q = p;
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 2; ++i) {
+        int cc = c0 + i, rr = r0 + j;
+        float xa = -sx + dx * (float)cc, ya = -sy + dy * (float)rr, xb = xa + dx, yb = ya + dy;
+        V3 v00 = v3(xa, ya, data[rr * ncol + cc] * sz), v10 = v3(xb, ya, data[rr * ncol + cc + 1] * sz);
+        V3 v01 = v3(xa, yb, data[(rr + 1) * ncol + cc] * sz), v11 = v3(xb, yb, data[(rr + 1) * ncol + cc + 1] * sz);
+        V3 qa = closest_on_triangle(p, v00, v10, v11);
+        V3 da = p - qa; float d2a = dot(da, da);
+        if (d2a < best) { best = d2a; q = qa; }
+        V3 qb = closest_on_triangle(p, v00, v11, v01);
+        V3 db = p - qb; float d2b = dot(db, db);
+        if (d2b < best) { best = d2b; q = qb; }
+      }
+    float dn = sqrtf(best);
+    n = v3(0, 0, 1);
+    if (!(dn < 1e-12f)) n = v3((p.x - q.x) / dn, (p.y - q.y) / dn, (p.z - q.z) / dn);
+    dist = dn - radius;
+  }
+  V3 pl = q + n * (0.5f * dist);
+  nrm = mulv(hmat, n);
+  pos = hpos + mulv(hmat, pl);
+  return true;
+}
+
 template <class C>
 __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane) {
   CPts pts; pts.cnt = 0;
@@ -744,6 +825,12 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane)
       float r = m.geom_size[3 * g2];
       float dist = dot(p2 - p1, n) - r;
       pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;
+    }
+    if constexpr (C::HFIELD) {
+      if (kind == PAIR_HFIELD_SPHERE) {
+        float dist; V3 pos, n;
+        if (hfield_sphere(m, p1, &s.x.a.gmat[9 * g1], p2, m.geom_size[3 * g2], dist, pos, n)) { pts.n = n; pts.dist[0] = dist; pts.pos[0] = pos; pts.cnt = 1; }
+      }
     }
   }
   // manifolds of the touching pairs, NSLOT at a time (usually one round: few pairs touch)

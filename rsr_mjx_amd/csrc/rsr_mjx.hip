@@ -20,7 +20,7 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
-                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true>;
+                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
@@ -957,6 +957,25 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
       if (bad) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the kernel assumes the target body's dofs share no chain, contact pair or equality with other dofs"); }
     }
   }
+  {  // height-field pairs: Go2 kernels only, one field, spheres no wider than a grid cell
+    int npk = 0, nh = 0, nsz = 0; const int* pk = static_cast<const int*>(m->find("pair_kind", &npk));
+    bool any_hf = false;
+    for (int i = 0; pk && i < npk; ++i) any_hf |= (pk[i] == rsr::PAIR_HFIELD_SPHERE);
+    if (any_hf) {
+      const int* hr = static_cast<const int*>(m->find("hfield_nrow", &nh));
+      const int* hc = static_cast<const int*>(m->find("hfield_ncol"));
+      const float* hs = static_cast<const float*>(m->find("hfield_size", &nsz));
+      int nd = 0; m->find("hfield_data", &nd);
+      bool okh = d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::HFIELD && hr && hc && hs && nh == 1 && nsz == 4 && hr[0] >= 3 && hc[0] >= 3 && nd == hr[0] * hc[0];
+      if (okh) {
+        const float cell = std::fmin(2.0f * hs[0] / (float)(hc[0] - 1), 2.0f * hs[1] / (float)(hr[0] - 1));
+        const int* g2 = static_cast<const int*>(m->find("pair_geom2"));
+        const float* gs = static_cast<const float*>(m->find("geom_size"));
+        for (int i = 0; i < npk; ++i) if (pk[i] == rsr::PAIR_HFIELD_SPHERE && 2.0f * gs[3 * g2[i]] > cell) okh = false;
+      }
+      if (!okh) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: height-field pairs need the Go2 kernels, exactly one height field of at least 3x3 samples, and spheres no wider than a grid cell"); }
+    }
+  }
   if (d.env_kind == rsr::ENV_GO2) { using C = rsr::Go2Dims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else { using C = rsr::CubeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
@@ -993,6 +1012,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(int, pair_b1) P(int, pair_b2) P(int, pair_root1) P(int, pair_root2) P(unsigned, pair_mask1) P(unsigned, pair_mask2)
   P(float, pair_tw) P(float, pair_incl) P(int, dof_rootid) P(int, dof_jtype) P(int, dof_k) P(int, dof_act) P(int, dof_afl)
   P(float, dof_afrange) P(int, body_jtype) P(int, body_qposadr) P(float, body_jpos) P(float, body_jaxis)
+  P(float, hfield_size) P(float, hfield_data) P(int, hfield_nrow) P(int, hfield_ncol)
   P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
   if (dm.env_kind == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2) {
     P(float, env_go2f) P(float, env_go2_scales) P(float, env_go2_home) P(float, env_go2_soft) P(int, env_go2i)

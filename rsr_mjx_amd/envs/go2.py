@@ -2,10 +2,11 @@
 (mujoco_playground/_src/locomotion/go2/joystick.py `Joystick.reset/step`, `_src/mjx_env.py` `State` with `.data`,
 `_src/registry.py` `load(name, config)`, `_src/wrapper.py` `wrap_for_brax_training`).
 
-Built: task "flat_terrain" (scene_mjx_feetonly_flat_terrain.xml), the 48-dim `state` observation (what
-`SelectObservationWrapper(obs_key="state")`, wrapper.py:77-104, hands to the learner), all 21 reward terms, command
-resampling, action / IMU delay FIFOs, Episode + AutoReset wrappers fused.  Not built yet: `privileged_state`,
-perturbation kicks (disabled in the reference default config), rough terrain (heightfield).
+Built: tasks "flat_terrain" and "rough_terrain" (scene_mjx_feetonly_{flat,rough}_terrain.xml; the rough scene's floor is
+a 256x256 height field), the 48-dim `state` observation (what `SelectObservationWrapper(obs_key="state")`,
+wrapper.py:77-104, hands to the learner), all 21 reward terms, command resampling, action / IMU delay FIFOs, the
+domain randomisation of go2/randomize.py, Episode + AutoReset wrappers fused.  Not built yet: `privileged_state`,
+perturbation kicks (disabled in the reference default config).
 """
 from __future__ import annotations
 
@@ -39,6 +40,9 @@ _INFO = dict(command=(0, 3), steps_until_next_cmd=(3, 4), last_act=(4, 16), last
              pert_steps=(132, 133), pert_dir=(133, 136), pert_mag=(136, 137), rng=(137, 139))
 
 
+_TASK_ASSET = {"flat_terrain": "go2_flat.npz", "rough_terrain": "go2_rough.npz"}
+
+
 class Joystick:
     """Env definition; `batched()` / `wrap_for_brax_training()` give the N-env GPU batch."""
 
@@ -47,11 +51,11 @@ class Joystick:
 
     def __init__(self, task: str = "flat_terrain", config: Optional[dict] = None,
                  config_overrides: Optional[Dict[str, Any]] = None, model_path: Optional[str] = None, device: str = "cuda:0"):
-        if task != "flat_terrain":
-            raise NotImplementedError(f"Go2 task {task!r}: only flat_terrain is built (rough terrain needs the heightfield)")
+        if task not in _TASK_ASSET:                                      # go2_constants.py:15-19 task_to_xml
+            raise KeyError(f"Go2 task {task!r}: built tasks are {sorted(_TASK_ASSET)}")
         self._config = cfg._merge(config or cfg.GO2_DEFAULT_CONFIG, config_overrides or {})
         if model_path is None:
-            base = CompiledModel.load(os.path.join(_ASSETS, "go2_flat.npz"))
+            base = CompiledModel.load(os.path.join(_ASSETS, _TASK_ASSET[task]))
         elif model_path.endswith(".npz"):
             base = CompiledModel.load(model_path)
         else:
@@ -174,7 +178,8 @@ def domain_randomize(sys, rng: np.ndarray) -> Dict[str, np.ndarray]:
                 dof_armature=arma, actuator_gainprm=gain, actuator_biasprm=bias, dof_damping=damp)
 
 
-_ENVS = {"Go2JoystickFlatTerrain": dict(task="flat_terrain")}      # _src/locomotion/__init__.py:16-26
+_ENVS = {"Go2JoystickFlatTerrain": dict(task="flat_terrain"),       # _src/locomotion/__init__.py:16-26
+         "Go2JoystickRoughTerrain": dict(task="rough_terrain")}
 
 
 def load(env_name: str, config: Optional[dict] = None, config_overrides: Optional[Dict[str, Any]] = None, **kw) -> Joystick:

@@ -913,7 +913,11 @@ class MjcfCompiler:
         sizes, nrow, ncol, data = [], [], [], []
         for hname in dict.fromkeys(used):
             h = self.hfields[hname]
-            img = read_png_gray(os.path.join(self.dir, self.meshdir, h["file"])).astype(np.float64)
+            # the reference loads assets through a name-keyed dict (base.py:18-24), so `file` may or may not repeat meshdir
+            cands = [os.path.join(self.dir, self.meshdir, h["file"]), os.path.join(self.dir, h["file"]),
+                     os.path.join(self.dir, self.meshdir, os.path.basename(h["file"]))]
+            path = next((c for c in cands if os.path.exists(c)), cands[0])
+            img = read_png_gray(path).astype(np.float64)
             # MuJoCo flips the image vertically and normalises to [0, 1]
             img = img[::-1, :]
             lo, hi = img.min(), img.max()

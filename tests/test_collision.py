@@ -117,3 +117,70 @@ def test_plane_box_deepest_vertices(lib64):
         pts = out.reshape(4, 4)[:n]
         assert n >= 1 and abs(pts[:, 0].min() - z.min()) < 1e-12
         assert np.all(pts[:, 0] < 0) and np.all(pts[:, 0] <= z.min() + 1e-3 + 1e-12)
+
+
+def _hfield_sphere(lib64, hsize, data, spos, radius, hpos=(0, 0, 0), hmat=np.eye(3)):
+    nrow, ncol = data.shape
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (hpos, hmat, spos, [radius])]
+    hs = np.ascontiguousarray(hsize, dtype=np.float32)
+    dat = np.ascontiguousarray(data, dtype=np.float32)
+    out, nrm = np.zeros(4), np.zeros(3)
+    n = lib64.oracle_hfield_sphere(a[0].ctypes.data, a[1].ctypes.data, hs.ctypes.data, nrow, ncol, dat.ctypes.data, a[2].ctypes.data,
+                                   a[3].ctypes.data, out.ctypes.data, nrm.ctypes.data)
+    return n, out[0], out[1:4].copy(), nrm.copy()
+
+
+def _surface_samples(hsize, data, cx, cy, span, k=24):
+    """dense point samples of the triangulated surface (diagonal (c,r)-(c+1,r+1)) around (cx, cy)"""
+    nrow, ncol = data.shape
+    sx, sy, sz = hsize[:3]
+    dx, dy = 2 * sx / (ncol - 1), 2 * sy / (nrow - 1)
+    pts = []
+    c0, r0 = int(np.floor((cx + sx) / dx)), int(np.floor((cy + sy) / dy))
+    u = np.linspace(0, 1, k)
+    U, V = np.meshgrid(u, u)
+    for r in range(max(r0 - span, 0), min(r0 + span + 1, nrow - 1)):
+        for c in range(max(c0 - span, 0), min(c0 + span + 1, ncol - 1)):
+            z00, z10, z01, z11 = (data[r, c] * sz, data[r, c + 1] * sz, data[r + 1, c] * sz, data[r + 1, c + 1] * sz)
+            Z = np.where(U >= V, z00 + (z10 - z00) * U + (z11 - z10) * V, z00 + (z11 - z01) * U + (z01 - z00) * V)
+            pts.append(np.stack([-sx + dx * (c + U), -sy + dy * (r + V), Z], -1).reshape(-1, 3))
+    return np.concatenate(pts)
+
+
+def test_hfield_sphere_closest_surface_point(lib64):
+    """Sphere vs height field: one contact at the closest point of the triangulated surface (brute-force samples);
+    flat field reduces to the plane-sphere closed form; centre below the surface gives the perpendicular depth."""
+    rng = np.random.default_rng(0)
+    hsize = np.array([1.0, 1.5, 0.3, 0.1])
+    data = rng.uniform(0, 1, size=(21, 17))
+    for _ in range(60):
+        c = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-1.2, 1.2), rng.uniform(0.0, 0.45)])
+        r = 0.04
+        n, dist, pos, nrm = _hfield_sphere(lib64, hsize, data, c, r)
+        assert n == 1 and abs(np.linalg.norm(nrm) - 1) < 1e-9
+        S = _surface_samples(hsize, data, c[0], c[1], 2)
+        dmin = np.linalg.norm(S - c, axis=1).min()
+        # height of the surface under the centre, from the same samples
+        near = S[np.argmin(np.linalg.norm(S[:, :2] - c[:2], axis=1))]
+        if c[2] > near[2] + 0.01:
+            assert abs(dist - (dmin - r)) < 4e-3, (dist, dmin - r)
+            q = pos - nrm * (0.5 * dist)                       # the surface point
+            assert np.linalg.norm(S - q, axis=1).min() < 6e-3
+            np.testing.assert_allclose(c - nrm * (dist + r), q, atol=1e-9)
+        elif c[2] < near[2] - 0.01:
+            assert dist < -r and nrm[2] > 0
+    flat = np.full((9, 9), 0.5)
+    n, dist, pos, nrm = _hfield_sphere(lib64, hsize, flat, [0.13, -0.2, 0.25], 0.05)
+    np.testing.assert_allclose([dist, *nrm], [0.25 - 0.15 - 0.05, 0, 0, 1], atol=1e-7)      # size is stored as float32
+    np.testing.assert_allclose(pos, [0.13, -0.2, 0.15 + 0.5 * dist], atol=1e-7)
+    n, dist, pos, nrm = _hfield_sphere(lib64, hsize, flat, [0.13, -0.2, 0.10], 0.05)      # centre under the surface
+    np.testing.assert_allclose([dist, *nrm], [-0.05 - 0.05, 0, 0, 1], atol=1e-7)
+    assert _hfield_sphere(lib64, hsize, flat, [1.2, 0, 0.2], 0.05)[0] == 0               # beyond the field: no contact
+    # a rotated, shifted field gives the rotated, shifted answer
+    ang = 0.4
+    Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    c = np.array([0.21, 0.33, 0.31])
+    n0, d0, p0, n0v = _hfield_sphere(lib64, hsize, data, c, 0.04)
+    off = np.array([0.5, -0.25, 0.125])
+    n1, d1, p1, n1v = _hfield_sphere(lib64, hsize, data, off + Rz @ c, 0.04, hpos=off, hmat=Rz)
+    np.testing.assert_allclose([d1, *p1, *n1v], [d0, *(off + Rz @ p0), *(Rz @ n0v)], atol=1e-12)
