@@ -66,6 +66,7 @@ enum rsr_field {
   RSR_F_INFO_STEPS, RSR_F_INFO_TRUNCATION, RSR_F_INFO_EPISODE_DONE, RSR_F_INFO_EPISODE_METRICS,
   RSR_F_FIRST_QPOS, RSR_F_FIRST_QVEL, RSR_F_FIRST_CTRL, RSR_F_FIRST_WARMSTART, RSR_F_FIRST_TIME,
   RSR_F_FIRST_XPOS, RSR_F_FIRST_SITE_XPOS, RSR_F_FIRST_OBS,
+  RSR_F_PRIVILEGED_OBS, RSR_F_FIRST_PRIVILEGED_OBS,  /* Go2 obs['privileged_state'], 123 floats (joystick.py:341-366) */
   RSR_F_STATS,             /* int32[4]: solver iters, line-search iters, active contacts, dropped contacts */
   RSR_F_COUNT
 };

@@ -22,7 +22,7 @@ _BATCH_FIELDS = [
     "info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita",
     "info_go2",
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
-    "first_obs",
+    "first_obs", "priv_obs", "first_priv_obs",
     "dr_geom_friction", "dr_body_mass", "dr_dof_damping", "dr_dof_frictionloss",
     "dr_body_ipos", "dr_qpos0", "dr_dof_armature", "dr_gainprm", "dr_biasprm",
 ]
@@ -100,6 +100,7 @@ class Oracle:
             info_target_base_pos=z(3), info_target_vertical_pos=z(3), info_target_w=z(), info_new_T_pos=z(2), info_T_pos=z(3), info_xita=z(), info_go2=z(144),
             first_qpos=z(self.nq), first_qvel=z(self.nv), first_ctrl=z(self.nu), first_warmstart=z(self.nv),
             first_time=z(), first_xpos=z(self.nbody, 3), first_site_xpos=z(self.nsite, 3), first_obs=z(self.obs_dim),
+            priv_obs=z(123), first_priv_obs=z(123),
             stats=np.zeros((n, 4), dtype=np.int32),
         )
         for k in _DR_KEYS:

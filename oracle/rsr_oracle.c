@@ -54,6 +54,7 @@ enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
 #define NEFC_MAX (1 + 2 * NV_MAX + 6 * NCON_MAX)
 #define OBS_MAX 64
 #define GO2_INFO 144
+#define GO2_PRIV 123   /* obs['privileged_state'] of the Go2 joystick env (joystick.py:341-366) */
 
 /* ------------------------------------------------------------------ blob */
 typedef struct { char name[40]; int32_t dtype, count, offset, reserved; } blob_entry;
@@ -236,6 +237,8 @@ typedef struct {
   real M[NV_MAX * NV_MAX], L[NV_MAX * NV_MAX];
   /* velocity stage */
   real cvel[NBODY_MAX * 6], cdof_dot[NV_MAX * 6];
+  int xfrc_body; real xfrc_force[3];     /* data.xfrc_applied: one body, force only (the Go2 perturbation kick); body <= 0: none */
+  real acc_site[3]; int acc_site_id;      /* accelerometer reading of site acc_site_id (< 0: not computed), from the last forward pass */
   real qfrc_bias[NV_MAX], qfrc_passive[NV_MAX], qfrc_actuator[NV_MAX], qfrc_smooth[NV_MAX], qacc_smooth[NV_MAX];
   /* contacts + constraint rows */
   int ncon, nefc, ne, nf, ncon_overflow;
@@ -251,6 +254,7 @@ typedef struct {
 static odata *odata_alloc(void) {
   odata *d = (odata *)calloc(1, sizeof(odata));
   d->efc_J = (real *)calloc((size_t)NEFC_MAX * NV_MAX, sizeof(real));
+  d->acc_site_id = -1;
   return d;
 }
 static void odata_free(odata *d) { if (d) { free(d->efc_J); free(d); } }
@@ -1099,10 +1103,14 @@ static void fwd_velocity_actuation(const omodel *m, odata *d) {
       d->qfrc_actuator[i] = clampr(d->qfrc_actuator[i], m->jnt_actfrcrange[2 * j], m->jnt_actfrcrange[2 * j + 1]);
   }
   /* qacc_smooth */
-  for (int i = 0; i < nv; i++) {
-    d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
-    d->qacc_smooth[i] = d->qfrc_smooth[i];
+  for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  if (d->xfrc_body > 0) {   /* support.xfrc_accumulate: J(xipos[body])^T force, MJX forward.fwd_acceleration */
+    real jacp[3 * NV_MAX];
+    jac_point(m, d, &d->xipos[3 * d->xfrc_body], d->xfrc_body, jacp, NULL);
+    for (int i = 0; i < nv; i++)
+      d->qfrc_smooth[i] += jacp[i] * d->xfrc_force[0] + jacp[nv + i] * d->xfrc_force[1] + jacp[2 * nv + i] * d->xfrc_force[2];
   }
+  for (int i = 0; i < nv; i++) d->qacc_smooth[i] = d->qfrc_smooth[i];
   chol_solve(d->L, d->qacc_smooth, nv, nv);
 }
 
@@ -1308,6 +1316,29 @@ static void solve(const omodel *m, odata *d) {
 }
 
 /* ------------------------------------------------------------------ forward + integrate (Appendix B.8) */
+/* accelerometer sensor (MuJoCo sensor_acc stage: mj_rnePostConstraint's cacc + mj_objectAcceleration with flg_local):
+ * cacc[body] = -gravity at the world, plus cdof_dot*qvel + cdof*qacc over the body's dof chain (com-based spatial
+ * acceleration about subtree_com[root]); moved to the site (lin + ang x dif), rotated into the site frame, plus the
+ * rotating-frame term w_local x v_local. */
+static void sensor_accelerometer(const omodel *m, odata *d) {
+  if (d->acc_site_id < 0) return;
+  const int sid = d->acc_site_id, body = m->site_bodyid[sid];
+  real cacc[6] = {0, 0, 0, -(real)m->gravity[0], -(real)m->gravity[1], -(real)m->gravity[2]};
+  int b = body;
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b > 0)
+    for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i])
+      for (int c = 0; c < 6; c++) cacc[c] += d->cdof_dot[6 * i + c] * d->qvel[i] + d->cdof[6 * i + c] * d->qacc[i];
+  const real *rc = &d->subtree_com[3 * m->body_rootid[body]], *pos = &d->site_xpos[3 * sid], *R = &d->site_xmat[9 * sid];
+  const real *cv = &d->cvel[6 * body];
+  real dif[3] = {pos[0] - rc[0], pos[1] - rc[1], pos[2] - rc[2]}, t[3], lin[3], lv[3], al[3], wl[3], vl[3];
+  v3cross(t, cacc, dif); for (int c = 0; c < 3; c++) lin[c] = cacc[3 + c] + t[c];
+  v3cross(t, cv, dif); for (int c = 0; c < 3; c++) lv[c] = cv[3 + c] + t[c];
+  mat_tmulv(al, R, lin); mat_tmulv(wl, R, cv); mat_tmulv(vl, R, lv);
+  v3cross(t, wl, vl);
+  for (int c = 0; c < 3; c++) d->acc_site[c] = al[c] + t[c];
+}
+
 static void forward(const omodel *m, odata *d) {
   kinematics(m, d);
   com_pos(m, d);
@@ -1316,6 +1347,7 @@ static void forward(const omodel *m, odata *d) {
   make_constraint(m, d);
   fwd_velocity_actuation(m, d);
   solve(m, d);
+  sensor_accelerometer(m, d);
 }
 
 static void advance(const omodel *m, odata *d, const real *qacc) {
@@ -1412,6 +1444,7 @@ typedef struct {
   float *info_target_base_pos, *info_target_vertical_pos, *info_target_w, *info_new_T_pos, *info_T_pos, *info_xita;
   float *info_go2;   /* Go2 joystick info block, GO2_INFO floats per env (layout: enum G2_*); NULL otherwise */
   float *first_qpos, *first_qvel, *first_ctrl, *first_warmstart, *first_time, *first_xpos, *first_site_xpos, *first_obs;
+  float *priv_obs, *first_priv_obs;   /* Go2 obs['privileged_state'] (GO2_PRIV floats) and its auto-reset copy; NULL otherwise */
   float *dr_geom_friction, *dr_body_mass, *dr_dof_damping, *dr_dof_frictionloss;  /* NULL = model values */
   float *dr_body_ipos, *dr_qpos0, *dr_dof_armature, *dr_gainprm, *dr_biasprm;      /* Go2 randomize.py leaves; NULL = model values */
   int *stats;   /* [n][4]: solver iterations, line-search iterations, ncon, overflow (last substep) */
@@ -1516,6 +1549,8 @@ static void reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], 
   memcpy(&s->first_xpos[e * m->nbody * 3], xpos, sizeof(float) * (size_t)m->nbody * 3);
   memcpy(&s->first_site_xpos[e * m->nsite * 3], sx, sizeof(float) * (size_t)m->nsite * 3);
   memcpy(&s->first_obs[e * m->obs_dim], &s->obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+  if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+    memcpy(&s->first_priv_obs[(size_t)e * GO2_PRIV], &s->priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
 }
 
 /* ------------------------------------------------------------------ step (cube_env.py:145-213 + wrappers) */
@@ -1617,6 +1652,8 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
     memcpy(xpos, &s->first_xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
     memcpy(sx, &s->first_site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
     memcpy(&s->obs[e * m->obs_dim], &s->first_obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+    if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+      memcpy(&s->priv_obs[(size_t)e * GO2_PRIV], &s->first_priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
   }
 }
 
@@ -1649,6 +1686,8 @@ static void wrappers_reset(const omodel *m, obatch *s, int e) {
   memcpy(&s->first_xpos[e * m->nbody * 3], &s->xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
   memcpy(&s->first_site_xpos[e * m->nsite * 3], &s->site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
   memcpy(&s->first_obs[e * m->obs_dim], &s->obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+  if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+    memcpy(&s->first_priv_obs[(size_t)e * GO2_PRIV], &s->priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
 }
 
 /* Episode + AutoReset post-step (brax.envs.training.wrap), shared by all envs */
@@ -1677,6 +1716,8 @@ static void wrappers_post(const omodel *m, obatch *s, int e, float reward) {
     memcpy(&s->xpos[e * m->nbody * 3], &s->first_xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
     memcpy(&s->site_xpos[e * m->nsite * 3], &s->first_site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
     memcpy(&s->obs[e * m->obs_dim], &s->first_obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
+    if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+      memcpy(&s->priv_obs[(size_t)e * GO2_PRIV], &s->first_priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
   }
 }
 
@@ -1804,10 +1845,10 @@ static void tshape_step_env(const omodel *m, obatch *s, int e, const float *acti
 enum { G2_CMD = 0, G2_STEPS_CMD = 3, G2_LAST_ACT = 4, G2_LAST_LAST_ACT = 16, G2_AIR = 28, G2_CONTACT_T = 32, G2_LAST_CONTACT = 36,
        G2_SWING = 40, G2_ACT_BUF = 44, G2_GYRO_BUF = 92, G2_LINVEL_BUF = 104, G2_GRAV_BUF = 116, G2_STEPS_PERT = 128,
        G2_PERT_DUR_S = 129, G2_PERT_DUR = 130, G2_SINCE_PERT = 131, G2_PERT_STEPS = 132, G2_PERT_DIR = 133, G2_PERT_MAG = 136,
-       G2_RNG = 137 };
+       G2_RNG = 137, G2_XFRC = 139 /* data.xfrc_applied[torso, :3]; zero again on auto-reset (it is part of `data`) */ };
 /* env_go2f: 0 ctrl_dt, 1 action_scale, 2 noise level, 3 n_joint_pos, 4 n_joint_vel, 5 n_gyro, 6 n_gravity, 7 n_linvel,
  *           8 tracking_sigma, 9 max_foot_height, 10..12 cmd_a, 13..15 cmd_b, 16 change_interval, 17..18 kick_wait,
- *           19..20 kick_durations, 21..22 velocity_kick
+ *           19..20 kick_durations, 21..22 velocity_kick, 23 torso subtree mass (body_subtreemass, joystick.py:104)
  * env_go2i: 0 action delay steps, 1 imu delay steps, 2 pert enable
  * env_ids : 0 imu site, 1..4 feet sites (FR FL RR RL), 5 floor geom, 6..9 feet geoms, 10 torso body
  * env_go2_scales: reward scales in reward_config order (= metrics order); env_go2_home: keyframe "home" qpos;
@@ -1821,7 +1862,7 @@ static inline void g2_set_key(float *info, const uint32_t key[2]) { memcpy(&info
 static float g2_uniform1(const uint32_t key[2], float lo, float hi) { float v; oracle_uniform(key, 1, &lo, &hi, 0, &v); return v; }
 
 typedef struct { float gyro[3], local_linvel[3], gravity[3], upvector[3], global_linvel[3], global_angvel[3], feet_vel[4][3],
-                 feet_z[4], act_force[NU_MAX]; int contact[4]; } g2_sensors;
+                 feet_z[4], act_force[NU_MAX], accel[3]; int contact[4]; } g2_sensors;
 
 static void g2_read_sensors(const omodel *m, const odata *d, g2_sensors *o) {
   const int imu = m->env_ids[0];
@@ -1842,6 +1883,7 @@ static void g2_read_sensors(const omodel *m, const odata *d, g2_sensors *o) {
     o->contact[f] = 0;
   }
   for (int u = 0; u < m->nu; u++) o->act_force[u] = (float)d->actuator_force[u];
+  for (int c = 0; c < 3; c++) o->accel[c] = (float)d->acc_site[c];
   /* collision.geoms_colliding(data, foot, floor): a contact of that pair with dist < 0 (_src/collision.py:6-18) */
   for (int i = 0; i < d->ncon; i++) {
     if (!(d->con[i].dist < 0)) continue;
@@ -1879,6 +1921,53 @@ static void g2_obs(const omodel *m, float *info, const float *qpos, const float 
 }
 
 /* joystick.py:123-203 */
+/* joystick.py:341-366: obs["privileged_state"] = state + un-noised, un-delayed readings.  Called right after g2_obs. */
+static void g2_priv_obs(const omodel *m, const float *info, const float *qpos, const float *qvel, const g2_sensors *sn, const float *obs,
+                        float *p) {
+  int k = 0;
+  for (int i = 0; i < 48; i++) p[k++] = obs[i];
+  for (int i = 0; i < 3; i++) p[k++] = sn->gyro[i];
+  for (int i = 0; i < 3; i++) p[k++] = sn->accel[i];
+  for (int i = 0; i < 3; i++) p[k++] = sn->gravity[i];
+  for (int i = 0; i < 3; i++) p[k++] = sn->local_linvel[i];
+  for (int i = 0; i < 3; i++) p[k++] = sn->global_angvel[i];
+  for (int i = 0; i < 12; i++) p[k++] = qpos[7 + i] - m->env_go2_home[7 + i];
+  for (int i = 0; i < 12; i++) p[k++] = qvel[6 + i];
+  for (int i = 0; i < 12; i++) p[k++] = sn->act_force[i];
+  for (int f = 0; f < 4; f++) p[k++] = info[G2_LAST_CONTACT + f];
+  for (int f = 0; f < 4; f++) for (int c = 0; c < 3; c++) p[k++] = sn->feet_vel[f][c];
+  for (int f = 0; f < 4; f++) p[k++] = info[G2_AIR + f];
+  for (int c = 0; c < 3; c++) p[k++] = info[G2_XFRC + c];
+  p[k++] = info[G2_SINCE_PERT] >= info[G2_STEPS_PERT] ? 1.0f : 0.0f;
+}
+
+/* joystick.py:594-644 _maybe_apply_perturbation: a half-sine force pulse on the torso every kick_wait_times seconds */
+static void g2_maybe_perturb(const omodel *m, float *info) {
+  const float *F = m->env_go2f;
+  if (info[G2_SINCE_PERT] >= info[G2_STEPS_PERT]) {
+    float t = info[G2_PERT_STEPS] * F[0];
+    volatile float ph = 3.14159265358979323846f * t;
+    float u_t = 0.5f * sinf(ph / info[G2_PERT_DUR_S]);
+    volatile float f1 = u_t * F[23]; volatile float f2 = f1 * info[G2_PERT_MAG];
+    float force = f2 / info[G2_PERT_DUR_S];
+    for (int c = 0; c < 3; c++) info[G2_XFRC + c] = force * info[G2_PERT_DIR + c];
+    if (info[G2_PERT_STEPS] >= info[G2_PERT_DUR]) info[G2_SINCE_PERT] = 0.0f;
+    info[G2_PERT_STEPS] += 1.0f;
+  } else {
+    uint32_t rng[2], ks[2][2];
+    g2_get_key(info, rng);
+    oracle_split(rng, 2, &ks[0][0]);
+    g2_set_key(info, ks[0]);
+    info[G2_SINCE_PERT] += 1.0f;
+    for (int c = 0; c < 3; c++) info[G2_XFRC + c] = 0.0f;
+    if (info[G2_SINCE_PERT] >= info[G2_STEPS_PERT]) {
+      float angle = g2_uniform1(ks[1], 0.0f, 6.2831855f);
+      info[G2_PERT_STEPS] = 0.0f;
+      info[G2_PERT_DIR] = cosf(angle); info[G2_PERT_DIR + 1] = sinf(angle); info[G2_PERT_DIR + 2] = 0.0f;
+    }
+  }
+}
+
 static void go2_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], odata *d) {
   const float *F = m->env_go2f;
   float *info = &s->info_go2[(size_t)e * GO2_INFO];
@@ -1910,6 +1999,7 @@ static void go2_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[
   for (int i = 0; i < m->nv; i++) { s->qvel[e * m->nv + i] = qvel[i]; s->qacc_warmstart[e * m->nv + i] = 0; }
   for (int i = 0; i < m->nu; i++) s->ctrl[e * m->nu + i] = qpos[7 + i];
   load_env(m, s, e, d);
+  d->acc_site_id = m->env_ids[0]; d->xfrc_body = 0;
   forward(m, d);
   store_pipeline(m, s, e, d);
   oracle_split(rng, 4, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
@@ -1931,6 +2021,7 @@ static void go2_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[
   g2_sensors sn;
   g2_read_sensors(m, d, &sn);
   g2_obs(m, info, &s->qpos[e * m->nq], &s->qvel[e * m->nv], &sn, &s->obs[e * m->obs_dim]);
+  if (s->priv_obs) g2_priv_obs(m, info, &s->qpos[e * m->nq], &s->qvel[e * m->nv], &sn, &s->obs[e * m->obs_dim], &s->priv_obs[(size_t)e * GO2_PRIV]);
   s->reward[e] = 0; s->done[e] = 0;
   wrappers_reset(m, s, e);
 }
@@ -1945,6 +2036,7 @@ static void go2_step_env(const omodel *m, obatch *s, int e, const float *action,
   float *info = &s->info_go2[(size_t)e * GO2_INFO];
   const float *act_in = &action[e * nu];
   if ((m->wrap_flags & 2) != 0) { if (s->done[e] != 0) s->info_steps[e] = 0; s->done[e] = 0; }
+  if (m->env_go2i[2]) g2_maybe_perturb(m, info);
   /* action delay FIFO (:207-215) */
   float actual[NU_MAX];
   const int adel = m->env_go2i[0];
@@ -1955,6 +2047,9 @@ static void go2_step_env(const omodel *m, obatch *s, int e, const float *action,
   } else for (int i = 0; i < nu; i++) actual[i] = act_in[i];
   load_env(m, s, e, d);
   for (int i = 0; i < nu; i++) { volatile float sc = actual[i] * F[1]; d->ctrl[i] = home[7 + i] + sc; }
+  d->acc_site_id = m->env_ids[0];
+  d->xfrc_body = m->env_go2i[2] ? m->env_ids[10] : 0;
+  for (int c = 0; c < 3; c++) d->xfrc_force[c] = info[G2_XFRC + c];
   for (int f = 0; f < m->n_frames; f++) step_physics(m, d);
   store_pipeline(m, s, e, d);
   const float *qpos = &s->qpos[e * m->nq], *qvel = &s->qvel[e * m->nv];
@@ -1979,6 +2074,7 @@ static void go2_step_env(const omodel *m, obatch *s, int e, const float *action,
     if (sn.feet_z[f] > info[G2_SWING + f]) info[G2_SWING + f] = sn.feet_z[f];
   }
   g2_obs(m, info, qpos, qvel, &sn, &s->obs[e * m->obs_dim]);
+  if (s->priv_obs) g2_priv_obs(m, info, qpos, qvel, &sn, &s->obs[e * m->obs_dim], &s->priv_obs[(size_t)e * GO2_PRIV]);
   float done = sn.upvector[2] < 0.0f ? 1.0f : 0.0f;
   /* ---- reward terms ---- */
   const float *cmd = &info[G2_CMD];
@@ -2094,6 +2190,7 @@ static void go2_step_env(const omodel *m, obatch *s, int e, const float *action,
   met[RW_COUNT] = swing_mean / 4.0f;
   s->reward[e] = reward; s->done[e] = done;
   wrappers_post(m, s, e, reward);
+  if ((m->wrap_flags & 2) != 0 && s->done[e] != 0) for (int c = 0; c < 3; c++) info[G2_XFRC + c] = 0.0f;   /* data <- first data */
 }
 
 /* ------------------------------------------------------------------ exported batch entry points */
@@ -2163,6 +2260,7 @@ int oracle_debug_forward(const omodel *m, const real *qpos, const real *qvel, co
   for (int i = 0; i < m->nq; i++) d->qpos0[i] = m->qpos0[i];
   for (int i = 0; i < m->nu * 3; i++) { d->gainprm[i] = m->actuator_gainprm[i]; d->biasprm[i] = m->actuator_biasprm[i]; }
   d->time = 0;
+  d->acc_site_id = m->nsite > 0 ? (m->env_kind == ENV_GO2 ? m->env_ids[0] : 0) : -1;
   if (do_step) step_physics(m, d); else forward(m, d);
   return d->nefc;
 }
@@ -2175,7 +2273,7 @@ int oracle_debug_get(const omodel *m, const char *name, double *out, int cap) {
   G("xmat", d->xmat, 9 * m->nbody) G("xipos", d->xipos, 3 * m->nbody) G("ximat", d->ximat, 9 * m->nbody)
   G("geom_xpos", d->geom_xpos, 3 * m->ngeom) G("geom_xmat", d->geom_xmat, 9 * m->ngeom) G("site_xpos", d->site_xpos, 3 * m->nsite)
   G("site_xmat", d->site_xmat, 9 * m->nsite) G("site_linvel", d->site_linvel, 3 * m->nsite) G("site_angvel", d->site_angvel, 3 * m->nsite)
-  G("actuator_force", d->actuator_force, m->nu)
+  G("actuator_force", d->actuator_force, m->nu) G("accelerometer", d->acc_site, 3)
   G("subtree_com", d->subtree_com, 3 * m->nbody) G("cinert", d->cinert, 10 * m->nbody) G("cdof", d->cdof, 6 * m->nv)
   G("cvel", d->cvel, 6 * m->nbody) G("cdof_dot", d->cdof_dot, 6 * m->nv)
   G("M", d->M, m->nv * m->nv) G("qfrc_bias", d->qfrc_bias, m->nv) G("qfrc_passive", d->qfrc_passive, m->nv)

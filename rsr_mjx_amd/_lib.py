@@ -14,7 +14,7 @@ FIELDS = [
     "info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita", "info_go2",
     "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics",
     "first_qpos", "first_qvel", "first_ctrl", "first_warmstart", "first_time", "first_xpos", "first_site_xpos",
-    "first_obs", "stats",
+    "first_obs", "privileged_obs", "first_privileged_obs", "stats",
 ]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 DEBUG_FLOATS = 8192

@@ -71,6 +71,7 @@ struct Layout {
   int target_pos, new_cube_pos, site_pos, cube_pos, last_action, steps, truncation, episode_done, episode_metrics;
   int target_base_pos, target_vertical_pos, target_w, new_T_pos, T_pos, xita;     // T-shape env info
   int go2_info;                                                                  // Go2 joystick info block (144 floats)
+  int priv_obs, f_priv_obs;                                                      // Go2 obs['privileged_state'] (123 floats) and its first-state copy
   int f_qpos, f_qvel, f_ctrl, f_warm, f_time, f_xpos, f_site_xpos, f_obs;
   int stats;
   int rec;            // floats per env (multiple of 16)
@@ -94,6 +95,7 @@ template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_
 struct Dims {
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
+  static constexpr bool XFRC = NINFO_ > 0;           // xfrc_applied on one body and the accelerometer bias are compiled in (Go2)
   static constexpr bool HFIELD = HFIELD_;            // sphere / height-field pairs are compiled in
   static constexpr bool DREX = DREX_;                // per-env body_ipos / qpos0 / armature / actuator gains staged in LDS
   // dofs [ISO0, ISO1) never share a constraint row or a kinematic chain with the others (the Airbot target body: it only
@@ -237,6 +239,10 @@ struct Smem {
   float egeom[(C::NEG > 0 ? C::NEG : 1) * 3];          // world positions of the env's geoms of interest
   float smat[C::NS * 9], slinvel[C::NS * 3], sangvel[C::NS * 3];   // site frames / object velocities (sensor sources)
   float aforce[C::NU];                                 // actuator_force of the last forward pass
+  // Dims::XFRC: external force on one body (data.xfrc_applied, force part), and for the accelerometer the velocity-product
+  // part of body acc_body's spatial acceleration ([0, -g] + sum cdof_dot*qvel over its chain) from the last forward pass
+  float xfrc[3], accb[6];
+  int xfrc_body, acc_body;
   float ginfo[C::NINFO > 0 ? C::NINFO : 1];            // env info block staged in LDS for the whole step (Go2)
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
   float M[C::NV * C::LD], T[C::NV * C::LD];
@@ -921,6 +927,12 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
 #pragma unroll
       for (int c = 0; c < 6; ++c) a[c] += s.x.a.cdofdot[6 * i + c] * qd;
     }
+    if constexpr (C::XFRC) {
+      if (lane == s.acc_body) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s.accb[c] = a[c];
+      }
+    }
     float f1[6], f2[6];
     inert_mul(f1, &s.x.a.cinert[10 * lane], a);
     inert_mul(f2, &s.x.a.cinert[10 * lane], &s.x.a.cvel[6 * lane]);
@@ -961,6 +973,14 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     }
     if (m.dof_afl[i]) act = clampf(act, m.dof_afrange[2 * i], m.dof_afrange[2 * i + 1]);
     smooth = passive - bias + act;
+    if constexpr (C::XFRC) {     // support.xfrc_accumulate: J(xipos[body])^T force
+      const int xb = s.xfrc_body;
+      if (xb > 0 && ((m.body_dofmask[xb] >> i) & 1)) {
+        V3 off = ld3(&s.x.a.xipos[3 * xb]) - ld3(&s.com[3 * m.body_rootid[xb]]);
+        V3 jp = ld3(&s.cdof[6 * i + 3]) + cross(ld3(&s.cdof[6 * i]), off);
+        smooth += jp.x * s.xfrc[0] + jp.y * s.xfrc[1] + jp.z * s.xfrc[2];
+      }
+    }
   }
   (void)ctrl_u;
   return smooth;

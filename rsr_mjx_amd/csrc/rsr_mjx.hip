@@ -124,7 +124,8 @@ __device__ void store_pipeline(Smem<C>& s, float* rec, const Layout& L, int lane
 enum { G2_CMD = 0, G2_STEPS_CMD = 3, G2_LAST_ACT = 4, G2_LAST_LAST_ACT = 16, G2_AIR = 28, G2_CONTACT_T = 32, G2_LAST_CONTACT = 36,
        G2_SWING = 40, G2_ACT_BUF = 44, G2_GYRO_BUF = 92, G2_LINVEL_BUF = 104, G2_GRAV_BUF = 116, G2_STEPS_PERT = 128,
        G2_PERT_DUR_S = 129, G2_PERT_DUR = 130, G2_SINCE_PERT = 131, G2_PERT_STEPS = 132, G2_PERT_DIR = 133, G2_PERT_MAG = 136,
-       G2_RNG = 137 };
+       G2_RNG = 137, G2_XFRC = 139 /* data.xfrc_applied[torso, :3] */ };
+constexpr int GO2_PRIV = 123;    // obs['privileged_state'], joystick.py:341-366
 enum { RW_TRACK_LIN = 0, RW_TRACK_ANG, RW_LIN_VEL_Z, RW_ANG_VEL_XY, RW_ORIENT, RW_DOF_LIMITS, RW_POSE, RW_TERM, RW_STAND_STILL,
        RW_TORQUES, RW_ACTION_RATE, RW_ENERGY, RW_FEET_CLEAR, RW_FEET_HEIGHT, RW_FEET_SLIP, RW_FEET_AIR, RW_ALL_FEET_AIR,
        RW_SYM_GAIT, RW_LR_SYM, RW_FB_SYM, RW_FEET_OFF_STILL, RW_COUNT };
@@ -146,7 +147,7 @@ __device__ __forceinline__ float tf_uniform(uint32_t k0, uint32_t k1, int n, flo
   return lane < n ? uniform_from_bits(bits[lane], lo, hi) : 0.0f;
 }
 
-struct G2Sens { float gyro[3], linvel[3], gravity[3], up[3], glin[3], gang[3]; };
+struct G2Sens { float gyro[3], linvel[3], gravity[3], up[3], glin[3], gang[3], accel[3]; };
 
 template <class C>
 __device__ void go2_sensors(const DModel& m, const Smem<C>& s, G2Sens& o) {
@@ -193,6 +194,45 @@ __device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* ob
   if (lane < 3) obs_lds[45 + lane] = s.ginfo[G2_CMD + lane];
   if (lane == 0) { s.ginfo[G2_RNG] = __uint_as_float(rng0); s.ginfo[G2_RNG + 1] = __uint_as_float(rng1); }
   WSYNC();
+}
+
+// accelerometer of the IMU site (MuJoCo sensor_acc: rne_postconstraint cacc + objectAcceleration, local frame):
+// cacc = accb (velocity-product part saved by smooth_forces) + sum over the body's chain of cdof * qacc, moved to the site
+// (lin + ang x dif), rotated into the site frame, plus w_local x v_local.  Wave-cooperative; every lane gets the result.
+template <class C>
+__device__ void go2_accelerometer(const DModel& m, const Smem<C>& s, int lane, float qacc_i, G2Sens& o) {
+  const int imu = m.env_ids[0], b = m.site_bodyid[imu];
+  const bool on = lane < C::NV && ((m.body_dofmask[b] >> lane) & 1);
+  float c6[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) c6[c] = wave_sum(on ? s.cdof[6 * lane + c] * qacc_i : 0.0f) + s.accb[c];
+  V3 dif = ld3(&s.spos[3 * imu]) - ld3(&s.com[3 * m.body_rootid[b]]);
+  V3 ang = v3(c6[0], c6[1], c6[2]), lin = v3(c6[3], c6[4], c6[5]) + cross(ang, dif);
+  const float* R = &s.smat[9 * imu];
+  V3 w = ld3(&s.sangvel[3 * imu]), v = ld3(&s.slinvel[3 * imu]);
+  auto rt = [&](V3 x) { return v3(R[0] * x.x + R[3] * x.y + R[6] * x.z, R[1] * x.x + R[4] * x.y + R[7] * x.z, R[2] * x.x + R[5] * x.y + R[8] * x.z); };
+  V3 al = rt(lin), wl = rt(w), vl = rt(v), cr = cross(wl, vl);
+  o.accel[0] = al.x + cr.x; o.accel[1] = al.y + cr.y; o.accel[2] = al.z + cr.z;
+}
+
+// joystick.py:341-366: element t of obs["privileged_state"]; read right after go2_obs (info: old last_contact, air + dt)
+template <class C>
+__device__ float go2_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& sn, const float* obs_lds, int t) {
+  if (t < 48) return obs_lds[t];
+  t -= 48;
+  if (t < 3) return sn.gyro[t];
+  if (t < 6) return sn.accel[t - 3];
+  if (t < 9) return sn.gravity[t - 6];
+  if (t < 12) return sn.linvel[t - 9];
+  if (t < 15) return sn.gang[t - 12];
+  if (t < 27) return s.qpos[7 + t - 15] - m.env_go2_home[7 + t - 15];
+  if (t < 39) return s.qvel[6 + t - 27];
+  if (t < 51) return s.aforce[t - 39];
+  if (t < 55) return s.ginfo[G2_LAST_CONTACT + t - 51];
+  if (t < 67) { int k = t - 55; return s.slinvel[3 * m.env_ids[1 + k / 3] + k % 3]; }
+  if (t < 71) return s.ginfo[G2_AIR + t - 67];
+  if (t < 74) return s.ginfo[G2_XFRC + t - 71];
+  return s.ginfo[G2_SINCE_PERT] >= s.ginfo[G2_STEPS_PERT] ? 1.0f : 0.0f;
 }
 
 // ---------------------------------------------------------------- reset kernel
@@ -533,6 +573,7 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
   }
   WSYNC();
   if (lane < C::NU) s.ctrl[lane] = s.qpos[7 + lane];          // mjx_env.init(..., ctrl = qpos[7:])
+  if (lane == 0) { s.xfrc_body = 0; s.acc_body = m.site_bodyid[m.env_ids[0]]; s.xfrc[0] = s.xfrc[1] = s.xfrc[2] = 0.0f; }
   WSYNC();
   float Mrow[C::NV], warm = 0.0f;
   FwdOut<C> f;
@@ -566,7 +607,9 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
   WSYNC();
   G2Sens sn;
   go2_sensors<C>(m, s, sn);
+  go2_accelerometer<C>(m, s, lane, f.qacc, sn);
   go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  for (int t = lane; t < GO2_PRIV; t += 64) { float v = go2_priv_elem<C>(m, s, sn, obs_lds, t); rec[L.priv_obs + t] = v; rec[L.f_priv_obs + t] = v; }
   store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
   for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];
   for (int t = lane; t < C::OBS; t += 64) { rec[L.obs + t] = obs_lds[t]; rec[L.f_obs + t] = obs_lds[t]; }
@@ -614,6 +657,46 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;
   const float act_in = lane < C::NU ? a.action[(size_t)e * C::NU + lane] : 0.0f;
   WSYNC();
+  // ---- perturbation kick (:594-644): half-sine force pulse on the torso, or wait and draw the next direction ----
+  if (m.env_go2i[2]) {
+    const bool kicking = s.ginfo[G2_SINCE_PERT] >= s.ginfo[G2_STEPS_PERT];      // wave-uniform (LDS)
+    if (kicking) {
+      WSYNC();
+      if (lane == 0) {
+#pragma clang fp contract(off)
+        float t = s.ginfo[G2_PERT_STEPS] * dt;
+        float ph = 3.14159265358979323846f * t;
+        float u_t = 0.5f * sinf(ph / s.ginfo[G2_PERT_DUR_S]);
+        float f1 = u_t * F[23]; float f2 = f1 * s.ginfo[G2_PERT_MAG];
+        float force = f2 / s.ginfo[G2_PERT_DUR_S];
+        for (int c = 0; c < 3; ++c) s.ginfo[G2_XFRC + c] = force * s.ginfo[G2_PERT_DIR + c];
+        if (s.ginfo[G2_PERT_STEPS] >= s.ginfo[G2_PERT_DUR]) s.ginfo[G2_SINCE_PERT] = 0.0f;
+        s.ginfo[G2_PERT_STEPS] += 1.0f;
+      }
+    } else {
+      uint32_t k2[2][2];
+      tf_split<2>(__float_as_uint(s.ginfo[G2_RNG]), __float_as_uint(s.ginfo[G2_RNG + 1]), bits, lane, k2);
+      float angle = rdlane(tf_uniform(k2[1][0], k2[1][1], 1, 0.0f, 6.2831855f, bits, lane), 0);
+      WSYNC();
+      if (lane == 0) {
+        s.ginfo[G2_RNG] = __uint_as_float(k2[0][0]); s.ginfo[G2_RNG + 1] = __uint_as_float(k2[0][1]);
+        float since = s.ginfo[G2_SINCE_PERT] + 1.0f;
+        s.ginfo[G2_SINCE_PERT] = since;
+        s.ginfo[G2_XFRC] = 0.0f; s.ginfo[G2_XFRC + 1] = 0.0f; s.ginfo[G2_XFRC + 2] = 0.0f;
+        if (since >= s.ginfo[G2_STEPS_PERT]) {
+          s.ginfo[G2_PERT_STEPS] = 0.0f;
+          s.ginfo[G2_PERT_DIR] = cosf(angle); s.ginfo[G2_PERT_DIR + 1] = sinf(angle); s.ginfo[G2_PERT_DIR + 2] = 0.0f;
+        }
+      }
+    }
+    WSYNC();
+  }
+  if (lane == 0) {
+    s.acc_body = m.site_bodyid[m.env_ids[0]];
+    s.xfrc_body = m.env_go2i[2] ? m.env_ids[10] : 0;
+    s.xfrc[0] = s.ginfo[G2_XFRC]; s.xfrc[1] = s.ginfo[G2_XFRC + 1]; s.xfrc[2] = s.ginfo[G2_XFRC + 2];
+  }
+  WSYNC();
   // ---- action delay FIFO (:207-215) and motor targets (:216) ----
   const int adel = m.env_go2i[0];
   float actual = act_in;
@@ -648,6 +731,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   // ---- sensors of the last forward pass, IMU FIFOs (:220-235) ----
   G2Sens sn;
   go2_sensors<C>(m, s, sn);
+  go2_accelerometer<C>(m, s, lane, f.qacc, sn);
   const int idel = m.env_go2i[1];
   if (idel > 0) {
     float v = 0.0f;
@@ -680,6 +764,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
   WSYNC();
   go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  float priv[2];                                              // this lane's elements of privileged_state (info as of now)
+  priv[0] = go2_priv_elem<C>(m, s, sn, obs_lds, lane);
+  priv[1] = lane + 64 < GO2_PRIV ? go2_priv_elem<C>(m, s, sn, obs_lds, lane + 64) : 0.0f;
   float done = sn.up[2] < 0.0f ? 1.0f : 0.0f;
   // ---- rewards (:367-593): scalar algebra on lane 0, evaluated op by op ----
   float reward = 0.0f;
@@ -817,13 +904,18 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
   WSYNC();
   done = rdlane(done, 0);
+  if (wrap_autoreset && done != 0.0f && lane < 3) s.ginfo[G2_XFRC + lane] = 0.0f;     // xfrc_applied belongs to `data`: back to the first state's zeros
+  WSYNC();
   for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];       // info is never reset by AutoReset
   if (wrap_autoreset && done != 0.0f) {
     for (int t = lane; t < L.persist_end; t += 64) rec[t] = rec[L.f_qpos + t];
     for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = rec[L.f_obs + t];
+    for (int t = lane; t < GO2_PRIV; t += 64) rec[L.priv_obs + t] = rec[L.f_priv_obs + t];
   } else {
     store_pipeline<C>(s, rec, L, lane, warm, time);
     for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = obs_lds[t];
+    rec[L.priv_obs + lane] = priv[0];
+    if (lane + 64 < GO2_PRIV) rec[L.priv_obs + lane + 64] = priv[1];
   }
 #ifdef RSR_PROFILE
   PROF(PS_EPILOGUE)
@@ -894,6 +986,7 @@ static Layout make_layout(const rsr_dims& d) {
   L.target_base_pos = take(3); L.target_vertical_pos = take(3); L.target_w = take(1); L.new_T_pos = take(2);
   L.T_pos = take(3); L.xita = take(1);
   L.go2_info = take(d.env_kind == rsr::ENV_GO2 ? 144 : 0);
+  L.priv_obs = take(d.env_kind == rsr::ENV_GO2 ? 123 : 0); L.f_priv_obs = take(d.env_kind == rsr::ENV_GO2 ? 123 : 0);
   L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
   L.stats = take(4);
   L.rec = (o + 15) & ~15;
@@ -1193,6 +1286,8 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_FIRST_XPOS: off = L.f_xpos; w = d.nbody * 3; break;
     case RSR_F_FIRST_SITE_XPOS: off = L.f_site_xpos; w = d.nsite * 3; break;
     case RSR_F_FIRST_OBS: off = L.f_obs; w = d.obs_dim; break;
+    case RSR_F_PRIVILEGED_OBS: off = L.priv_obs; w = d.env_kind == rsr::ENV_GO2 ? 123 : 0; break;
+    case RSR_F_FIRST_PRIVILEGED_OBS: off = L.f_priv_obs; w = d.env_kind == rsr::ENV_GO2 ? 123 : 0; break;
     case RSR_F_STATS: off = L.stats; w = 4; break;
     default: return fail(RSR_ERR_ARG, "rsr_view: unknown field id");
   }

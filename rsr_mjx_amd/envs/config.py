@@ -164,10 +164,23 @@ def go2_apply_overrides(m: CompiledModel, config: dict) -> CompiledModel:
     return CompiledModel(name=m.name, arrays=A, names=m.names)
 
 
+def _subtree_mass(m: CompiledModel, body: int) -> float:
+    par, mass = m.arrays["body_parentid"], m.arrays["body_mass"]
+    total = 0.0
+    for b in range(body, m.nbody):
+        a = b
+        while a > body:
+            a = int(par[a])
+        if a == body:
+            total += float(mass[b])
+    return total
+
+
+GO2_PRIV_OBS_DIM = 123      # obs["privileged_state"], joystick.py:341-366
+
+
 def go2_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto_reset: bool = False) -> Dict[str, np.ndarray]:
     """`m` must already carry the base.py overrides (go2_apply_overrides)."""
-    if config["pert_config"]["enable"]:
-        raise NotImplementedError("perturbation kicks (joystick.py:594-644) are not built; the reference default disables them")
     if config["action_repeat"] != 1:
         raise NotImplementedError("action_repeat != 1")
     A = m.arrays
@@ -181,7 +194,8 @@ def go2_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto
     nz, rc, cc, pc, dc = (config[k] for k in ("noise_config", "reward_config", "command_config", "pert_config", "delay_config"))
     f = np.array([config["ctrl_dt"], config["action_scale"], nz["level"], nz["scales"]["joint_pos"], nz["scales"]["joint_vel"],
                   nz["scales"]["gyro"], nz["scales"]["gravity"], nz["scales"]["linvel"], rc["tracking_sigma"], rc["max_foot_height"],
-                  *cc["a"], *cc["b"], cc["change_interval"], *pc["kick_wait_times"], *pc["kick_durations"], *pc["velocity_kick"]],
+                  *cc["a"], *cc["b"], cc["change_interval"], *pc["kick_wait_times"], *pc["kick_durations"], *pc["velocity_kick"],
+                  _subtree_mass(m, m.id("body", "trunk"))],      # joystick.py:104 body_subtreemass[torso]
                  dtype=np.float32)
     flags = (WRAP_EPISODE if episode_length > 0 else 0) | (WRAP_AUTORESET if auto_reset else 0)
     return dict(

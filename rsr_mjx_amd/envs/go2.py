@@ -5,8 +5,8 @@
 Built: tasks "flat_terrain" and "rough_terrain" (scene_mjx_feetonly_{flat,rough}_terrain.xml; the rough scene's floor is
 a 256x256 height field), the 48-dim `state` observation (what `SelectObservationWrapper(obs_key="state")`,
 wrapper.py:77-104, hands to the learner), all 21 reward terms, command resampling, action / IMU delay FIFOs, the
-domain randomisation of go2/randomize.py, Episode + AutoReset wrappers fused.  Not built yet: `privileged_state`,
-perturbation kicks (disabled in the reference default config).
+domain randomisation of go2/randomize.py, the 123-dim `privileged_state` (accelerometer via the post-constraint body
+accelerations), perturbation kicks (`pert_config.enable`), Episode + AutoReset wrappers fused.
 """
 from __future__ import annotations
 
@@ -37,7 +37,8 @@ _INFO = dict(command=(0, 3), steps_until_next_cmd=(3, 4), last_act=(4, 16), last
              feet_contact_time=(32, 36), last_contact=(36, 40), swing_peak=(40, 44), action_buffer=(44, 92),
              gyro_buffer=(92, 104), linvel_buffer=(104, 116), gravity_buffer=(116, 128), steps_until_next_pert=(128, 129),
              pert_duration_seconds=(129, 130), pert_duration=(130, 131), steps_since_last_pert=(131, 132),
-             pert_steps=(132, 133), pert_dir=(133, 136), pert_mag=(136, 137), rng=(137, 139))
+             pert_steps=(132, 133), pert_dir=(133, 136), pert_mag=(136, 137), rng=(137, 139),
+             xfrc_applied_torso=(139, 142))      # data.xfrc_applied[torso, :3] (zeroed again by auto-reset)
 
 
 _TASK_ASSET = {"flat_terrain": "go2_flat.npz", "rough_terrain": "go2_rough.npz"}
@@ -72,6 +73,11 @@ class Joystick:
     @property
     def observation_size(self) -> int:
         return self._obs_dim
+
+    @property
+    def observation_sizes(self) -> Dict[str, tuple]:
+        """the reference's dict-valued observation_size (_src/mjx_env.py:143-149)"""
+        return {"state": (self._obs_dim,), "privileged_state": (cfg.GO2_PRIV_OBS_DIM,)}
 
     @property
     def action_size(self) -> int:
@@ -116,9 +122,12 @@ class Go2Batched(BatchedEnv):
                         episode_metrics={"sum_reward": em[:, 0], "length": em[:, 1],
                                          **{name: em[:, 2 + i] for i, name in enumerate(cfg.GO2_METRICS)}})
         if self.auto_reset:
-            info["first_obs"] = v["first_obs"]
+            info["first_obs"] = {"state": v["first_obs"], "privileged_state": v["first_privileged_obs"]}
         st = State(pipeline_state=data, obs=v["obs"], reward=v["reward"][:, 0], done=v["done"][:, 0], metrics=metrics, info=info)
         st.data = data                      # Playground name of the physics state
+        # joystick.py:363-366 returns both observations; `obs` above is the one SelectObservationWrapper(obs_key="state")
+        # hands on, `obs_dict` the full reference dict (asymmetric actor-critic reads "privileged_state")
+        st.obs_dict = {"state": v["obs"], "privileged_state": v["privileged_obs"]}
         return st
 
 

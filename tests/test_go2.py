@@ -249,15 +249,73 @@ def test_go2_rough_terrain_oracle(oracle_mod):
     assert (fp[..., 2] > cell_lo - 0.005).all()                                      # no foot sank through its cell
 
 
+def test_go2_privileged_state_and_kicks(go2_model, oracle_mod):
+    """joystick.py:341-366 layout of obs['privileged_state'] and :594-644 the kick state machine, replayed in numpy
+    from the oracle's own info / sensor outputs."""
+    from rsr_mjx_amd.envs import config
+    over = {"pert_config": {"enable": True, "kick_wait_times": [0.1, 0.3], "velocity_kick": [2.0, 5.0]}}
+    blob = make_go2_blob(go2_model, episode_length=1000, auto_reset=True, overrides=over)
+    orc = oracle_mod.Oracle(blob)
+    n = 16
+    st = orc.new_state(n)
+    orc.reset(st, prng.split(prng.PRNGKey(3), n))
+    home = go2_model.arrays["key_qpos"][go2_model.names["key"]["home"]].astype(f32)
+    mass = f32(config._subtree_mass(go2_model, go2_model.id("body", "trunk")))
+    assert abs(mass - go2_model.arrays["body_mass"][1:].sum()) < 1e-4
+    P = st["priv_obs"]
+    np.testing.assert_array_equal(P[:, :48], st["obs"])
+    np.testing.assert_array_equal(st["first_priv_obs"], P)
+    np.testing.assert_array_equal(P[:, 63:75], st["qpos"][:, 7:] - home[7:])           # joint angles - default pose
+    np.testing.assert_array_equal(P[:, 75:87], st["qvel"][:, 6:])
+    assert not P[:, 99:103].any() and not P[:, 115:123].any()                           # last_contact, air time, xfrc, flag at reset
+    assert np.abs(P[:, 51:54]).max() < 200 and np.isfinite(P).all()
+    rng = np.random.default_rng(1)
+    kicked = 0
+    for t in range(60):
+        pre = st["info_go2"].copy()
+        a = np.clip(rng.normal(size=(n, 12)) * 0.3, -1, 1).astype(f32)
+        orc.step(st, a)
+        post = st["info_go2"]
+        P = st["priv_obs"]
+        for e in range(n):
+            if st["done"][e]:
+                np.testing.assert_array_equal(P[e], st["first_priv_obs"][e]); assert not post[e, 139:142].any(); continue
+            since, until, steps_p, dur, dur_s, mag = pre[e, 131], pre[e, 128], pre[e, 132], pre[e, 130], pre[e, 129], pre[e, 136]
+            if since >= until:                                           # apply_pert
+                u_t = f32(0.5) * np.sin(f32(np.pi) * f32(steps_p * f32(0.02)) / dur_s, dtype=f32)
+                force = u_t * mass * mag / dur_s
+                np.testing.assert_allclose(post[e, 139:142], force * pre[e, 133:136], rtol=2e-5, atol=1e-5)
+                assert post[e, 132] == steps_p + 1 and post[e, 131] == (0 if steps_p >= dur else since)
+                kicked += 1
+            else:                                                        # wait
+                assert post[e, 131] == since + 1 and not post[e, 139:142].any()
+                if since + 1 >= until:
+                    assert post[e, 132] == 0 and abs(np.linalg.norm(post[e, 133:135]) - 1) < 1e-6 and post[e, 135] == 0
+            np.testing.assert_array_equal(P[e, 119:122], post[e, 139:142])
+            assert P[e, 122] == float(post[e, 131] >= post[e, 128])
+            np.testing.assert_array_equal(P[e, 99:103], pre[e, 36:40])          # last_contact as it was before this step's update
+            np.testing.assert_array_equal(P[e, :48], st["obs"][e])
+            np.testing.assert_array_equal(P[e, 63:75], st["qpos"][e, 7:] - home[7:])
+    assert kicked > 20
+    # a kick moves the base: same keys and actions with kicks disabled end elsewhere
+    orc0 = oracle_mod.Oracle(make_go2_blob(go2_model, episode_length=1000, auto_reset=True))
+    s0 = orc0.new_state(n); orc0.reset(s0, prng.split(prng.PRNGKey(3), n))
+    rng = np.random.default_rng(1)
+    for t in range(60):
+        orc0.step(s0, np.clip(rng.normal(size=(n, 12)) * 0.3, -1, 1).astype(f32))
+    assert np.abs(s0["qpos"][:, :2] - st["qpos"][:, :2]).max() > 0.02
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,randomize", [("Flat", False), ("Flat", True), ("Rough", True)])
-def test_go2_hip_parity(oracle_mod, task, randomize):
+@pytest.mark.parametrize("task,randomize,kicks", [("Flat", False, False), ("Flat", True, True), ("Rough", True, False)])
+def test_go2_hip_parity(oracle_mod, task, randomize, kicks):
     """BASELINE configs[3] family (Go2JoystickFlatTerrain): reset bit-exact in the PRNG-only parts, teacher-forced steps.
     The Go2 solve is intentionally unconverged (iterations=1, ls_iterations=5), so velocities carry the usual fp32 noise."""
     import torch
     from rsr_mjx_amd.envs import go2
     n = 512
-    jenv = go2.load(f"Go2Joystick{task}Terrain")
+    over = {"pert_config": {"enable": True, "kick_wait_times": [0.1, 0.4], "velocity_kick": [1.0, 4.0]}} if kicks else None
+    jenv = go2.load(f"Go2Joystick{task}Terrain", config_overrides=over)
     dr = go2.domain_randomize(jenv.sys, prng.split(prng.PRNGKey(12), n)) if randomize else None
     env = go2.wrap_for_brax_training(jenv, n, episode_length=1000, randomization_fn=(lambda sys: dr) if randomize else None)
     assert env.observation_size == 48 and env.action_size == 12 and abs(env.dt - 0.02) < 1e-12
@@ -269,7 +327,10 @@ def test_go2_hip_parity(oracle_mod, task, randomize):
     orc.reset(st, keys)
     state = env.reset(keys)
     torch.cuda.synchronize()
-    get = lambda k: env.view(k).cpu().numpy().reshape(st[k].shape)
+    gname = {"priv_obs": "privileged_obs", "first_priv_obs": "first_privileged_obs"}
+    get = lambda k: env.view(gname.get(k, k)).cpu().numpy().reshape(st[k].shape)
+    np.testing.assert_allclose(get("priv_obs"), st["priv_obs"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_array_equal(get("first_priv_obs"), get("priv_obs"))
     for k in ("qvel", "ctrl", "obs", "first_obs"):
         np.testing.assert_array_equal(get(k), st[k], err_msg=k)
     np.testing.assert_array_equal(get("info_go2")[:, :137], st["info_go2"][:, :137])
@@ -277,14 +338,14 @@ def test_go2_hip_parity(oracle_mod, task, randomize):
     np.testing.assert_allclose(get("qpos"), st["qpos"], atol=1e-6)
     fields = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs", "reward", "done", "metrics", "info_go2",
               "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
-              "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs"]
+              "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs", "priv_obs", "first_priv_obs"]
     serr = lambda a, b: (np.abs(a.astype(np.float64) - b).reshape(n, -1) / np.maximum(1.0, np.abs(b.astype(np.float64)).reshape(n, -1).max(1, keepdims=True))).max(1)
     rng = np.random.default_rng(11)
     for depth in (0, 5, 40):
         for _ in range(depth):
             orc.step(st, np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32))
         for k in fields:
-            env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+            env.view(gname.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
         st64 = {k: (v.copy() if v is not None else None) for k, v in st.items()}
         before = {k: (v.copy() if v is not None else None) for k, v in st.items()}
         a = np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
@@ -295,10 +356,17 @@ def test_go2_hip_parity(oracle_mod, task, randomize):
             np.testing.assert_array_equal(get(k), st[k], err_msg=k)
         np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
         np.testing.assert_array_equal(get("info_go2")[:, :4], st["info_go2"][:, :4])                  # command, timer: PRNG only
-        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel"):
+        if kicks:
+            np.testing.assert_allclose(get("info_go2")[:, 128:137], st["info_go2"][:, 128:137], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(get("info_go2")[:, 139:142], st["info_go2"][:, 139:142], rtol=1e-5, atol=1e-4)
+            assert depth == 0 or np.abs(st["info_go2"][:, 139:142]).max() > 1.0 or depth < 40
+        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel", "priv_obs"):
             eg, ec = serr(get(k), st[k]), serr(st[k], st64[k])
-            allowed = max(1, int(0.01 * n), int(2.0 * np.sum(ec > 1e-5)))
-            assert np.sum(eg > 1e-5) <= allowed, (depth, k, int(np.sum(eg > 1e-5)), allowed)
+            # privileged_state carries the accelerometer: an acceleration-level reading (qacc of the one-iteration solve),
+            # one derivative noisier than the velocities the other fields hold
+            thr = 3e-5 if k == "priv_obs" else 1e-5
+            allowed = max(1, int(0.01 * n), int(2.0 * np.sum(ec > thr)))
+            assert np.sum(eg > thr) <= allowed, (depth, k, int(np.sum(eg > thr)), allowed)
             bound = 1e-4 + 3.0 * ec.max()
             for w in np.nonzero(eg > bound)[0]:
                 # A larger deviation is accepted only where the dynamics themselves are discontinuous at this state (on the
@@ -313,3 +381,37 @@ def test_go2_hip_parity(oracle_mod, task, randomize):
                 assert task == "Rough" and eg[w] <= 3.0 * sens + 1e-4, (depth, k, int(w), float(eg[w]), sens, float(ec.max()))
     assert set(state.info) >= {"command", "last_act", "feet_air_time", "action_buffer", "gyro_buffer", "rng", "steps", "truncation"}
     assert state.info["action_buffer"].shape == (n, 4, 12) and len(state.metrics) == 22
+
+
+def test_accelerometer_is_site_acceleration_minus_gravity(go2_model, oracle_mod):
+    """a13: the accelerometer (rne_postconstraint cacc + objectAcceleration) equals R^T (d/dt v_site - g): finite
+    difference of the IMU site's world velocity over one very small Euler step (fp64 oracle), in the air and on the ground."""
+    from rsr_mjx_amd.envs import config
+    m = config.go2_apply_overrides(go2_model, config._merge(config.GO2_DEFAULT_CONFIG, {"sim_dt": 1e-6, "ctrl_dt": 1e-6}))
+    orc = oracle_mod.Oracle(make_go2_blob(m, overrides={"sim_dt": 1e-6, "ctrl_dt": 1e-6}), "f64")
+    rng = np.random.default_rng(3)
+    home = m.arrays["key_qpos"][m.names["key"]["home"]]
+    imu = m.id("site", "imu")
+    for z in (0.6, 0.27):
+        for _ in range(4):
+            q = home.copy(); q[2] = z
+            q[3:7] += rng.normal(size=4) * 0.2; q[3:7] /= np.linalg.norm(q[3:7])
+            q[7:] += rng.normal(size=12) * 0.1
+            v = rng.normal(size=18) * 1.0
+            ctrl = q[7:] + rng.normal(size=12) * 0.2
+            orc.forward(q, v, ctrl)
+            acc = orc.get("accelerometer")
+            R = orc.get("site_xmat").reshape(-1, 3, 3)[imu]
+            v0 = orc.get("site_linvel").reshape(-1, 3)[imu]
+            ncon = int((orc.get("efc_pos").size))
+            orc.forward(q, v, ctrl, step=True)
+            q1, v1 = orc.get("qpos"), orc.get("qvel")
+            orc.forward(q1, v1, ctrl)
+            v1s = orc.get("site_linvel").reshape(-1, 3)[imu]
+            a_world = (v1s - v0) / 1e-6
+            expect = R.T @ (a_world - np.array([0, 0, -9.81]))
+            np.testing.assert_allclose(acc, expect, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(expect).max()))
+    # at rest in the air with no actuation error the trunk is in free fall: reading ~ 0 + joint reaction effects only
+    q = home.copy(); q[2] = 1.0
+    orc.forward(q, np.zeros(18), q[7:])
+    assert np.abs(orc.get("accelerometer")).max() < 1.0
