@@ -141,7 +141,7 @@ def main():
     env_steps = float(metrics_all[:, 0].sum().item())
 
     if rank == 0:
-        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2044, "go2rough": 2044}[args.workload]
+        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536}[args.workload]
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()
@@ -164,7 +164,7 @@ def main():
                             f"actions N(0,{act_std}) clipped to +-1",
                 "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
                 "kernel": {"cube": "rsr::step_kernel<CubeDims, ENV_CUBE>", "tshape": "rsr::step_kernel<TShapeDims, ENV_TSHAPE>",
-                           "go2": "rsr::go2_step_kernel<Go2Dims>"}[args.workload] + " (one wavefront per env)",
+                           "go2": "rsr::go2_step_kernel<Go2Dims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>"}[args.workload] + " (one wavefront per env)",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
                 "mean_newton_iters_last_substep": stats[0], "mean_linesearch_iters_last_substep": stats[1],
                 "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3],

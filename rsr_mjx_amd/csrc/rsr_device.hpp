@@ -190,7 +190,7 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
-       PS_INTEG, PS_EPILOGUE, PS_COUNT };
+       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_COUNT };
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
@@ -439,50 +439,55 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
 }
 
 // =====================================================================================
-// in-register Cholesky, lane i = row i.  a[] holds row i (lower part used); on return a[] holds
-// row i of L, lt[] holds row i of L^T (column i of L) fetched through the LDS scratch T.
+// in-register factorisation H = L D L^T (square-root free Cholesky), lane i = row i.  a[] holds row i of H (lower part
+// used); on return a[k] holds the UNIT lower factor L[i][k] for k < i and zero elsewhere, lt[k] holds L[k][i] for k > i
+// (row i of L^T, fetched through the LDS scratch T) and zero elsewhere, and the return value is 1/D[i] of this lane.
+// The zeros let the substitutions run without any lane selects: one v_readlane and one v_fma per step, which is the
+// whole dependent chain (the scaled form L L^T needs a multiply by 1/L[k][k] and two selects inside each step).
 // =====================================================================================
 template <class C, bool MASS_ONLY = false>
-__device__ __forceinline__ void chol_factor(float (&a)[C::NV], float (&lt)[C::NV], float* T, int lane) {
+__device__ __forceinline__ float chol_factor(float (&a)[C::NV], float (&lt)[C::NV], float* T, int lane) {
+  float dinv = 0.0f;
 #pragma unroll
   for (int k = 0; k < C::NV; ++k) {
     float piv = rdlane(a[k], k);
     piv = piv > 0.0f ? piv : RSR_MINVAL;
-    float inv = __builtin_amdgcn_rsqf(piv);     // v_rsq_f32 (1 ulp) + one Newton step: 1/sqrt(piv) without the IEEE sqrt/div sequences
-    inv = inv * (1.5f - 0.5f * piv * inv * inv);
-    a[k] = (lane == k) ? inv : a[k] * inv;      // column k of L below the diagonal; the diagonal slot keeps 1/L[k][k]
+    float r = __builtin_amdgcn_rcpf(piv);        // v_rcp_f32 (1 ulp) + one Newton step
+    r = r + r * (1.0f - piv * r);
+    if (lane == k) dinv = r;
+    const float u = a[k];                        // unscaled column k: u_i = H'[i][k]
+    a[k] = (lane > k) ? u * r : 0.0f;            // unit-lower column
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {
       if (!(MASS_ONLY ? C::same_tree(j, k) : C::coupled(j, k))) continue;   // L[j][k] is a structural zero (folds at compile time)
-      float ljk = rdlane(a[k], j);
-      a[j] -= a[k] * ljk;                       // rows i >= j use it; others hold garbage never read
+      float ujk = rdlane(u, j);
+      a[j] -= a[k] * ujk;                        // rows i >= j use it; others hold garbage never read
     }
   }
   // transpose through LDS: T[k][i] = L[i][k]
   if (lane < C::NV) {
 #pragma unroll
-    for (int k = 0; k < C::NV; ++k) T[k * C::LD + lane] = (k < lane) ? a[k] : 0.0f;
+    for (int k = 0; k < C::NV; ++k) T[k * C::LD + lane] = a[k];
   }
   WSYNC();
   if (lane < C::NV) {
 #pragma unroll
-    for (int k = 0; k < C::NV; ++k) lt[k] = T[lane * C::LD + k];   // lt[k] = L[k][lane] (k >= lane)
+    for (int k = 0; k < C::NV; ++k) lt[k] = T[lane * C::LD + k];   // lt[k] = L[k][lane] for k > lane, else 0
+  } else {
+#pragma unroll
+    for (int k = 0; k < C::NV; ++k) lt[k] = 0.0f;
   }
   WSYNC();
+  return dinv;
 }
-// solves L L^T x = b; lane i holds b_i in x and receives x_i.  a[k] of lane k holds 1/L[k][k].
+// solves L D L^T x = b; lane i holds b_i in x and receives x_i.
 template <class C>
-__device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float (&lt)[C::NV], float x, int lane) {
+__device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float (&lt)[C::NV], float dinv, float x, int lane) {
 #pragma unroll
-  for (int k = 0; k < C::NV; ++k) {          // forward: L y = b
-    float yk = rdlane(x, k) * rdlane(a[k], k);
-    x = (lane == k) ? yk : ((lane > k) ? x - a[k] * yk : x);
-  }
+  for (int k = 0; k < C::NV; ++k) x -= a[k] * rdlane(x, k);          // forward, unit lower: lanes <= k hold a[k] = 0
+  x *= dinv;
 #pragma unroll
-  for (int k = C::NV - 1; k >= 0; --k) {     // backward: L^T x = y
-    float xk = rdlane(x, k) * rdlane(a[k], k);
-    x = (lane == k) ? xk : ((lane < k) ? x - lt[k] * xk : x);
-  }
+  for (int k = C::NV - 1; k >= 0; --k) x -= lt[k] * rdlane(x, k);    // backward, unit upper: lanes >= k hold lt[k] = 0
   return x;
 }
 

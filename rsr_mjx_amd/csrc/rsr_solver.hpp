@@ -176,8 +176,8 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
 // Sparse rows are rank-1 updates; a contact adds B^T W B with B its four base rows and W the arrow matrix
 //   W_nn = sum hw,  W_nk = mu_k (hw_k+ - hw_k-),  W_kk = mu_k^2 (hw_k+ + hw_k-)   (k = tangent 1, tangent 2, torsion).
 template <class C>
-__device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
-                                               float (&a)[C::NV], float (&lt)[C::NV]) {
+__device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
+                                               float (&a)[C::NV], float (&lt)[C::NV] PROF_ARG) {
   constexpr int NBLK = (C::NV + 1) / 2;
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
@@ -206,6 +206,7 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
   }
   const int nc = compact_list<1>(s.clist, lane, con, -1);
   WSYNC();
+  PROF(PS_H_PREP)
   int bi = 0;
   while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
   int bj = lane - bi * (bi + 1) / 2;
@@ -223,6 +224,7 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
       h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
     }
   }
+  PROF(PS_H_SPARSE)
   for (int k = 0; k < nc; ++k) {
     int c = s.clist[k];
     const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LD];
@@ -240,6 +242,7 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
     }
     h00 += ni0 * u0n + a00; h01 += ni0 * u1n + a01; h10 += ni1 * u0n + a10; h11 += ni1 * u1n + a11;
   }
+  PROF(PS_H_CONTACT)
   if (blk) {
     s.T[i0 * C::LD + j0] = h00; s.T[(i0 + 1) * C::LD + j0] = h10; s.T[(i0 + 1) * C::LD + j0 + 1] = h11;
     if (bi != bj) s.T[i0 * C::LD + j0 + 1] = h01;     // diagonal blocks: (i0, i0+1) is upper, never read
@@ -248,7 +251,10 @@ __device__ __forceinline__ void hessian_factor(Smem<C>& s, int lane, int nefc, i
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) a[j] = (lane < C::NV && j <= lane) ? s.T[lane * C::LD + j] : 0.0f;
   WSYNC();
-  chol_factor<C>(a, lt, s.T, lane);
+  PROF(PS_H_XCHG)
+  const float dinv = chol_factor<C>(a, lt, s.T, lane);
+  PROF(PS_H_CHOL)
+  return dinv;
 }
 
 struct SolveStats { int niter, ls_total; };
@@ -288,8 +294,8 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
   PROF(PS_SOLVE_INIT)
-  hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt);
-  float search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+  float dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+  float search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
   PROF(PS_HESS)
   const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
@@ -323,6 +329,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     n2 = wave_sum(n2) + fabsf(g2);
     // Only for converging solves: with iterations == 1 (Go2) the reference's truncated procedure IS the answer.
     const float NOISE = m.iterations > 1 ? 1.1920929e-7f : 0.0f;
+    PROF(PS_LS_SETUP)
     LSPoint p0 = ls_point<C>(lane, nefc, 0.0f, jaref, jv, rr, gauss, g1, g2);
     LSPoint lo = ls_point<C>(lane, nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), jaref, jv, rr, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
@@ -366,8 +373,8 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
     PROF(PS_UPD)
-    hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt);
-    search = dofl ? -chol_solve<C>(a, lt, grad, lane) : 0.0f;
+    dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+    search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
     PROF(PS_HESS)
     ++iter;
   }
@@ -398,8 +405,8 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   float a[C::NV], lt[C::NV];
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] : 0.0f;
-  chol_factor<C, true>(a, lt, s.T, lane);
-  float a0 = lane < C::NV ? chol_solve<C>(a, lt, fs, lane) : 0.0f;
+  const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
+  float a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
   PROF(PS_CHOLM)
   collision<C>(m, s, lane);
   PROF(PS_COLL)
@@ -466,8 +473,8 @@ __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane,
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] + (j == lane ? dd : 0.0f) : 0.0f;
-    chol_factor<C, true>(a, lt, s.T, lane);
-    qacc = lane < C::NV ? chol_solve<C>(a, lt, f.fsmooth + f.qfc, lane) : 0.0f;
+    const float dinv_i = chol_factor<C, true>(a, lt, s.T, lane);
+    qacc = lane < C::NV ? chol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane) : 0.0f;
   }
   WSYNC();
   if (lane < C::NV) s.qvel[lane] += qacc * m.timestep;

@@ -15,7 +15,9 @@ from rsr_mjx_amd import prng
 from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
 
 NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "smooth_forces", "chol_M+solve",
-         "solver_init", "hessian+factor+solve", "linesearch", "update_constraint", "integrate", "epilogue+store"]
+         "solver_init", "hessian: solve only", "linesearch: p0, lo, iterations", "update_constraint", "integrate", "epilogue+store",
+         "hessian: weights+compaction", "hessian: sparse rows", "hessian: contacts", "hessian: block exchange", "hessian: cholesky",
+         "linesearch: setup (jdot, M.v, sums)"]
 n = 8192
 envdef = AirbotPlayBase()
 dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
