@@ -251,6 +251,9 @@ struct Smem {
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int lim_jnt[C::NL > 0 ? C::NL : 1];
+  // dof of every friction / limit row (their Jacobian row is a single +-1 there) and the Hessian's diagonal accumulator
+  int sdof[C::NSP + 1];
+  float dgw[C::NV];
   float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
   float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction
@@ -1057,12 +1060,13 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     if (j2 >= 0) s.x.b.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
     s.x.b.J[e * LD + m.jnt_dofadr[j1]] = 1.0f;
   }
-  if (lane < C::NF) s.x.b.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f;
+  if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f; s.sdof[r_fric + lane] = m.fric_dofs[lane]; }
   if (lane < nl) {
     int j = s.lim_jnt[lane];
     float q = s.qpos[m.jnt_qposadr[j]];
     float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
     s.x.b.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
+    s.sdof[r_lim + lane] = m.jnt_dofadr[j];
   }
   // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {

@@ -173,8 +173,12 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
 }
 
 // H = M + J^T diag(hw) J as 2x2 blocks (lane = block of the lower triangle), then factor.
-// Sparse rows are rank-1 updates; a contact adds B^T W B with B its four base rows and W the arrow matrix
-//   W_nn = sum hw,  W_nk = mu_k (hw_k+ - hw_k-),  W_kk = mu_k^2 (hw_k+ + hw_k-)   (k = tangent 1, tangent 2, torsion).
+//  * friction and limit rows have a single +-1 entry, so their J^T hw J is just hw added to that dof's diagonal: one
+//    LDS float add per row into dgw[] (at most two rows share a dof, so the sum does not depend on their order);
+//  * equality rows (two entries) stay rank-1 updates;
+//  * a contact adds B^T W B with B its base rows and W the arrow matrix
+//      W_nn = sum hw,  W_nk = mu_k (hw_k+ - hw_k-),  W_kk = mu_k^2 (hw_k+ + hw_k-)   (k = tangent 1, tangent 2, torsion);
+//    all contacts are visited (an all-inactive pyramid has W = 0), which keeps the loop free of index loads.
 template <class C>
 __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
                                                float (&a)[C::NV], float (&lt)[C::NV] PROF_ARG) {
@@ -182,14 +186,13 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
   static_assert(C::NSP <= 64 && C::NCON <= 64, "one lane per sparse row / contact");
+  const int ncon = s.ncon, rcon = nefc - C::NPYR * ncon;
   WSYNC();
 #pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = hw[ch]; }
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r >= rcon && r < nefc) s.rw[r] = hw[ch]; }
+  if (lane < C::NV) s.dgw[lane] = 0.0f;
   WSYNC();
-  const int ncon = s.ncon, rcon = nefc - C::NPYR * ncon;
-  bool son[1] = {lane < rcon && s.rw[lane < rcon ? lane : 0] != 0.0f};
-  const int nsp = compact_list<1>(s.rlist, lane, son, C::NBASE);
-  bool con[1] = {false};
+  if (lane >= C::NEQ && lane < rcon && hw[0] != 0.0f) atomicAdd(&s.dgw[s.sdof[lane]], hw[0]);
   if (lane < ncon) {
     int r0 = rcon + C::NPYR * lane, b0 = rcon + C::NBC * lane;
     float* w = &s.wc[8 * lane];
@@ -202,9 +205,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
       w[C::NBC - 1 + k] = mu * mu * (hp + hm);
     }
     w[0] = wnn;
-    con[0] = wnn != 0.0f;
   }
-  const int nc = compact_list<1>(s.clist, lane, con, -1);
   WSYNC();
   PROF(PS_H_PREP)
   int bi = 0;
@@ -214,19 +215,16 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   int i0 = blk ? 2 * bi : 0, j0 = blk ? 2 * bj : 0;
   float h00 = s.M[i0 * C::LD + j0], h01 = s.M[i0 * C::LD + j0 + 1];
   float h10 = s.M[(i0 + 1) * C::LD + j0], h11 = s.M[(i0 + 1) * C::LD + j0 + 1];
-  for (int k = 0; k < nsp; k += 4) {
+  if (bi == bj) { h00 += s.dgw[i0]; h11 += s.dgw[i0 + 1]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int r = s.rlist[k + u];
-      const float* Jr = &s.x.b.J[r * C::LD];
-      float w = r < C::NBASE ? s.rw[r] : 0.0f;
-      float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
-      h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
-    }
+  for (int r = 0; r < C::NEQ; ++r) {
+    const float* Jr = &s.x.b.J[r * C::LD];
+    float w = rdlane(hw[0], r);
+    float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
+    h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
   }
   PROF(PS_H_SPARSE)
-  for (int k = 0; k < nc; ++k) {
-    int c = s.clist[k];
+  for (int c = 0; c < ncon; ++c) {
     const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LD];
     const float* w = &s.wc[8 * c];
     float ni0 = B[i0], ni1 = B[i0 + 1], nj0 = B[j0], nj1 = B[j0 + 1];
