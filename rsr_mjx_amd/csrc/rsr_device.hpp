@@ -61,6 +61,7 @@ struct DModel {
   float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
   int nfric, nlimit, maxdepth;
+  int max_sub, max_chain;       // longest body_submask (bodies >= 1) / dof-chain mask, in bits: trip bounds of for_bits4
   int env_kind, n_frames, episode_length, wrap_flags;
 };
 
@@ -186,6 +187,22 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define WSYNC() __syncthreads()
+
+// Visits the set bits of `mask` four candidates per trip: f(i, on) with on = false (and i = 0) once the mask is
+// exhausted.  The four LDS loads of a trip do not depend on each other, so they are in flight together and a walk over
+// n bits costs ceil(n/4) LDS latencies instead of n.  `nbits` is a wave-uniform upper bound of the popcount.
+template <class F>
+__device__ __forceinline__ void for_bits4(unsigned mask, int nbits, F&& f) {
+  for (int t = 0; t < nbits; t += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool on = mask != 0u;
+      const int i = on ? __builtin_ctz(mask) : 0;
+      mask &= mask - 1u;
+      f(i, on);
+    }
+  }
+}
 
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
@@ -378,11 +395,10 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   if (lane < C::NB) {
     unsigned mask = m.body_submask[lane];
     float mm = 0; V3 acc = v3(0, 0, 0);
-    while (mask) {
-      int k = __builtin_ctz(mask); mask &= mask - 1;
-      float mk = s.mass[k];
+    for_bits4(mask, lane == 0 ? C::NB : m.max_sub, [&](int k, bool on) {      // the world's subtree is every body
+      float mk = on ? s.mass[k] : 0.0f;
       mm += mk; acc = acc + ld3(&s.x.a.xipos[3 * k]) * mk;
-    }
+    });
     V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * lane]) : acc * (1.0f / mm);
     st3(&s.com[3 * lane], c);
   }
@@ -420,7 +436,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
     int b = t / 10, c = t - 10 * b;
     unsigned mask = b == 0 ? 0u : m.body_submask[b];
     float acc = 0;
-    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.x.a.cinert[10 * k + c]; }
+    for_bits4(mask, m.max_sub, [&](int k, bool on) { float v = s.x.a.cinert[10 * k + c]; acc += on ? v : 0.0f; });
     s.x.a.crb[t] = acc;
   }
   WSYNC();
@@ -429,14 +445,13 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
     float f[6];
     inert_mul(f, &s.x.a.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
     unsigned mask = m.dof_ancmask[i];
-    while (mask) {
-      int j = __builtin_ctz(mask); mask &= mask - 1;
+    const float arma = mdl_armature<C>(m, s, i);
+    for_bits4(mask, m.max_chain, [&](int j, bool on) {
       const float* cj = &s.cdof[6 * j];
       float v = f[0] * cj[0] + f[1] * cj[1] + f[2] * cj[2] + f[3] * cj[3] + f[4] * cj[4] + f[5] * cj[5];
-      if (j == i) v += mdl_armature<C>(m, s, i);
-      s.M[i * C::LD + j] = v;
-      s.M[j * C::LD + i] = v;
-    }
+      if (j == i) v += arma;
+      if (on) { s.M[i * C::LD + j] = v; s.M[j * C::LD + i] = v; }
+    });
   }
   WSYNC();
 }
@@ -892,12 +907,11 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
     float v[6] = {0, 0, 0, 0, 0, 0};
-    while (mask) {
-      int i = __builtin_ctz(mask); mask &= mask - 1;
-      float qd = s.qvel[i];
+    for_bits4(mask, m.max_chain, [&](int i, bool on) {
+      float qd = on ? s.qvel[i] : 0.0f;
 #pragma unroll
       for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
-    }
+    });
 #pragma unroll
     for (int c = 0; c < 6; ++c) s.x.a.cvel[6 * lane + c] = v[c];
   }
@@ -906,12 +920,11 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     unsigned mask = m.dof_velmask[lane];
     bool free_trans = (m.dof_jtype[lane] == JNT_FREE) && (m.dof_k[lane] < 3);
     float v[6] = {0, 0, 0, 0, 0, 0};
-    while (mask) {
-      int i = __builtin_ctz(mask); mask &= mask - 1;
-      float qd = s.qvel[i];
+    for_bits4(mask, m.max_chain, [&](int i, bool on) {
+      float qd = on ? s.qvel[i] : 0.0f;
 #pragma unroll
       for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
-    }
+    });
     float o[6];
     motion_cross(o, v, &s.cdof[6 * lane]);
 #pragma unroll
@@ -929,12 +942,11 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
     float a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-    while (mask) {
-      int i = __builtin_ctz(mask); mask &= mask - 1;
-      float qd = s.qvel[i];
+    for_bits4(mask, m.max_chain, [&](int i, bool on) {
+      float qd = on ? s.qvel[i] : 0.0f;
 #pragma unroll
       for (int c = 0; c < 6; ++c) a[c] += s.x.a.cdofdot[6 * i + c] * qd;
-    }
+    });
     if constexpr (C::XFRC) {
       if (lane == s.acc_body) {
 #pragma unroll
@@ -954,7 +966,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     int b = t / 6, c = t - 6 * b;
     unsigned mask = m.body_submask[b];
     float acc = 0;
-    while (mask) { int k = __builtin_ctz(mask); mask &= mask - 1; acc += s.x.a.cfrc[6 * k + c]; }
+    for_bits4(mask, m.max_sub, [&](int k, bool on) { float v = s.x.a.cfrc[6 * k + c]; acc += on ? v : 0.0f; });
     s.x.a.cfrcsum[t] = acc;
   }
   WSYNC();

@@ -1120,6 +1120,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   dm.iterations = I("opt_iterations")[0]; dm.ls_iterations = I("opt_ls_iterations")[0]; dm.integrator = I("opt_integrator")[0];
   dm.disable_eulerdamp = I("opt_disable_eulerdamp")[0]; dm.disable_refsafe = I("opt_disable_refsafe")[0];
   dm.nfric = I("counts2")[0]; dm.nlimit = I("counts2")[1]; dm.maxdepth = I("counts2")[2];
+  { int nc2 = 0; const int* c2 = static_cast<const int*>(m->find("counts2", &nc2)); dm.max_sub = nc2 > 5 ? c2[4] : 32; dm.max_chain = nc2 > 5 ? c2[5] : 32; }
   const int* ei = I("env_int");
   dm.env_kind = ei[0]; dm.n_frames = ei[1]; dm.episode_length = ei[2]; dm.wrap_flags = ei[3];
   return RSR_OK;

@@ -183,4 +183,7 @@ def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
     flat = flattened_tables(m, bdof)
     return dict(**flat, dof_ancmask=as_i32(anc), dof_velmask=as_i32(vel), body_dofmask=as_i32(bdof),
                 body_submask=as_i32(sub), fric_dofs=fric, limit_jnts=lim, body_depth=depth,
-                counts2=np.array([len(fric), len(lim), int(depth.max()), int(A["body_jntnum"].max())], dtype=np.int32))
+                counts2=np.array([len(fric), len(lim), int(depth.max()), int(A["body_jntnum"].max()),
+                                  # longest bit lists the kernel walks: subtree bodies (bodies >= 1), chain dofs
+                                  max([bin(int(x)).count("1") for x in sub[1:]] + [0]),
+                                  max([bin(int(x)).count("1") for x in list(bdof) + list(anc) + list(vel)] + [0])], dtype=np.int32))
