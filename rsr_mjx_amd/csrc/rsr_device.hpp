@@ -207,7 +207,7 @@ __device__ __forceinline__ void for_bits4(unsigned mask, int nbits, F&& f) {
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
-       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_COUNT };
+       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_COUNT };
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
@@ -838,7 +838,7 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
 }
 
 template <class C>
-__device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane PROF_ARG) {
   CPts pts; pts.cnt = 0;
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
@@ -862,6 +862,7 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane)
       }
     }
   }
+  PROF(PS_X0)
   // manifolds of the touching pairs, NSLOT at a time (usually one round: few pairs touch)
   unsigned long long pend = __ballot(job.kind != 0);
   while (pend) {
@@ -873,6 +874,7 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane)
     }
     pend = __ballot(job.kind != 0);
   }
+  PROF(PS_X1)
   // keep penetrating contacts only (result-neutral culling), compact in pair order
   int keep = 0;
   for (int i = 0; i < pts.cnt; ++i) if (pts.dist[i] - incl < 0.0f) keep++;
@@ -890,6 +892,7 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane)
   }
   if (lane == 0) { s.ncon = total < C::NCON ? total : C::NCON; s.ncon_drop = total > C::NCON ? total - C::NCON : 0; }
   WSYNC();
+  PROF(PS_X2)
 }
 
 // =====================================================================================
@@ -1041,7 +1044,7 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
 // aref -= bcoef * (J.qvel) once the base rows are in LDS (it owns the J.v machinery).
 template <class C>
 __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
-                               int& nbase_out) {
+                               int& nbase_out PROF_ARG) {
   constexpr int LD = C::LD;
   // active joint limits, compacted in joint order
   int lim_active = 0;
@@ -1080,6 +1083,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     s.x.b.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
     s.sdof[r_lim + lane] = m.jnt_dofadr[j];
   }
+  PROF(PS_X3)
   // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
@@ -1095,6 +1099,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     Jr[0 * LD] = dot(nn, jp); Jr[1 * LD] = dot(t1, jp); Jr[2 * LD] = dot(t2, jp);
     if constexpr (C::NBC > 3) Jr[3 * LD] = dot(nn, jr);
   }
+  PROF(PS_X4)
   // friction coefficient of each contact base row (normal: unused)
   for (int t = lane; t < ncon * C::NBC; t += 64) {
     int c = t / C::NBC, k = t - c * C::NBC;
@@ -1105,6 +1110,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     s.bmu[r_con + t] = k == 0 ? 0.0f : (k == 3 ? f1 : f0);
   }
   WSYNC();
+  PROF(PS_X5)
   // per-row regulariser and reference acceleration (the velocity term J.qvel is added by the caller)
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {

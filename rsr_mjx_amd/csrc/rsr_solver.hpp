@@ -69,31 +69,59 @@ __device__ __forceinline__ float rows_cost(int lane, int nefc, const float (&jar
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
-// Evaluates the 1-D cost model at NPT step sizes at once: per-row quadratic pieces are summed over the rows
-// owned by the lane, then the 3*NPT partial sums are reduced together (independent DPP chains overlap).
-template <class C, int NPT>
-__device__ __forceinline__ void ls_eval(int lane, int nefc, const float (&alpha)[NPT], const float (&jaref)[C::NCHUNK],
-                                        const float (&jv)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK], float g0, float g1,
-                                        float g2, LSPoint (&out)[NPT]) {
-  float q[NPT][3];
-#pragma unroll
-  for (int p = 0; p < NPT; ++p) q[p][0] = q[p][1] = q[p][2] = 0.0f;
+// Per-row constants of one line search (they do not depend on the step size): the quadratic piece b0 + b1 a + b2 a^2 of an
+// active row, and for the first chunk -- the only one that can hold equality and friction rows -- the two linear pieces
+// and their thresholds.  Row kinds are unified there as "lower linear piece if x <= -tlo, upper one if x >= thi, else
+// quadratic": friction rows have tlo = thi = R*floss; a unilateral row (limit, contact) has no lower piece (tlo = inf)
+// and a zero upper piece from thi = 0 on; an equality row has neither (tlo = thi = inf).
+template <class C>
+struct LSRows {
+  float ja[C::NCHUNK], v[C::NCHUNK], b0[C::NCHUNK], b1[C::NCHUNK], b2[C::NCHUNK];
+  float tlo, thi, c0m, c1m, c0p, c1p;        // chunk 0 only
+};
+template <class C>
+__device__ __forceinline__ void ls_prepare(int lane, int nefc, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
+                                           const RowRegs (&rr)[C::NCHUNK], LSRows<C>& o) {
+  static_assert(C::NEQ + C::NF <= 64, "equality and friction rows must sit in the first chunk");
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) {
-    if (64 * ch >= nefc) continue;            // wave-uniform
-    int r = lane + 64 * ch, kind = row_kind<C>(r);
     float ja = jaref[ch], v = jv[ch], D = rr[ch].D;
-    float b0 = 0.5f * ja * ja * D, b1 = v * ja * D, b2 = 0.5f * v * v * D;
-    float f = rr[ch].floss, rf = rr[ch].R * f;
+    o.ja[ch] = ja; o.v[ch] = v;
+    o.b0[ch] = 0.5f * ja * ja * D; o.b1[ch] = v * ja * D; o.b2[ch] = 0.5f * v * v * D;
+    if (lane + 64 * ch >= nefc) { o.b0[ch] = 0.0f; o.b1[ch] = 0.0f; o.b2[ch] = 0.0f; o.v[ch] = 0.0f; o.ja[ch] = 1.0f; }   // padding rows: inactive
+  }
+  const int kind = row_kind<C>(lane);
+  const float f = rr[0].floss, rf = rr[0].R * f, ja = jaref[0], v = jv[0];
+  o.tlo = kind == 1 ? rf : INFINITY;
+  o.thi = kind == 1 ? rf : (kind == 2 ? 0.0f : INFINITY);
+  o.c0m = f * (-0.5f * rf - ja); o.c1m = -f * v;
+  o.c0p = kind == 1 ? f * (-0.5f * rf + ja) : 0.0f; o.c1p = kind == 1 ? f * v : 0.0f;
+  if (lane >= nefc) { o.tlo = INFINITY; o.thi = INFINITY; }
+}
+
+// Evaluates the 1-D cost model at NPT step sizes at once: per-row pieces are summed over the rows owned by the lane, then
+// the 3*NPT partial sums are reduced together (independent DPP chains overlap).
+template <class C, int NPT>
+__device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], const LSRows<C>& w, float g0, float g1, float g2,
+                                        LSPoint (&out)[NPT]) {
+  float q[NPT][3];
 #pragma unroll
-    for (int p = 0; p < NPT; ++p) {
-      float x = ja + alpha[p] * v;
-      float a0 = b0, a1 = b1, a2 = b2;
-      if (kind == 1) {
-        if (x <= -rf) { a0 = f * (-0.5f * rf - ja); a1 = -f * v; a2 = 0; }
-        else if (x >= rf) { a0 = f * (-0.5f * rf + ja); a1 = f * v; a2 = 0; }
-      } else if (kind == 2 && !(x < 0.0f)) { a0 = a1 = a2 = 0; }
-      q[p][0] += a0; q[p][1] += a1; q[p][2] += a2;
+  for (int p = 0; p < NPT; ++p) {
+    // chunk 0: three pieces
+    float x = w.ja[0] + alpha[p] * w.v[0];
+    bool lo = x <= -w.tlo, hi = x >= w.thi;
+    q[p][0] = lo ? w.c0m : (hi ? w.c0p : w.b0[0]);
+    q[p][1] = lo ? w.c1m : (hi ? w.c1p : w.b1[0]);
+    q[p][2] = (lo || hi) ? 0.0f : w.b2[0];
+  }
+#pragma unroll
+  for (int ch = 1; ch < C::NCHUNK; ++ch) {
+    if (64 * ch >= nefc) continue;            // wave-uniform
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {           // unilateral rows only: quadratic while x < 0
+      float x = w.ja[ch] + alpha[p] * w.v[ch];
+      bool act = x < 0.0f;
+      q[p][0] += act ? w.b0[ch] : 0.0f; q[p][1] += act ? w.b1[ch] : 0.0f; q[p][2] += act ? w.b2[ch] : 0.0f;
     }
   }
 #pragma unroll
@@ -111,11 +139,10 @@ __device__ __forceinline__ void ls_eval(int lane, int nefc, const float (&alpha)
   }
 }
 template <class C>
-__device__ __forceinline__ LSPoint ls_point(int lane, int nefc, float alpha, const float (&jaref)[C::NCHUNK], const float (&jv)[C::NCHUNK],
-                                            const RowRegs (&rr)[C::NCHUNK], float g0, float g1, float g2) {
+__device__ __forceinline__ LSPoint ls_point(int nefc, float alpha, const LSRows<C>& w, float g0, float g1, float g2) {
   float al[1] = {alpha};
   LSPoint o[1];
-  ls_eval<C, 1>(lane, nefc, al, jaref, jv, rr, g0, g1, g2, o);
+  ls_eval<C, 1>(nefc, al, w, g0, g1, g2, o);
   return o[0];
 }
 
@@ -328,8 +355,10 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     // Only for converging solves: with iterations == 1 (Go2) the reference's truncated procedure IS the answer.
     const float NOISE = m.iterations > 1 ? 1.1920929e-7f : 0.0f;
     PROF(PS_LS_SETUP)
-    LSPoint p0 = ls_point<C>(lane, nefc, 0.0f, jaref, jv, rr, gauss, g1, g2);
-    LSPoint lo = ls_point<C>(lane, nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), jaref, jv, rr, gauss, g1, g2), hi;
+    LSRows<C> lw;
+    ls_prepare<C>(lane, nefc, jaref, jv, rr, lw);
+    LSPoint p0 = ls_point<C>(nefc, 0.0f, lw, gauss, g1, g2);
+    LSPoint lo = ls_point<C>(nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), lw, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     bool swap = true; int it = 0;
     while (true) {
@@ -342,7 +371,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
       if (uniform_i(ldone)) break;
       float al3[3] = {lo.alpha - lo.d0 * __builtin_amdgcn_rcpf(lo.d1), hi.alpha - hi.d0 * __builtin_amdgcn_rcpf(hi.d1), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
-      ls_eval<C, 3>(lane, nefc, al3, jaref, jv, rr, gauss, g1, g2, p3);
+      ls_eval<C, 3>(nefc, al3, lw, gauss, g1, g2, p3);
       LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
       bool s1 = (lo.d0 > 0.0f) || (lo.d0 < lo_next.d0);
       if (s1) lo = lo_next;
@@ -368,6 +397,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
     gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
     prev_cost = cost; cost = rc + gauss;
+    PROF(PS_X6)
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
     PROF(PS_UPD)
@@ -406,12 +436,12 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
   PROF(PS_CHOLM)
-  collision<C>(m, s, lane);
+  collision<C>(m, s, lane PROF_PASS);
   PROF(PS_COLL)
   RowRegs rr[C::NCHUNK];
   float bcoef[C::NCHUNK], jqv[C::NCHUNK];
   int nbase;
-  int nefc = make_constraint<C>(m, s, lane, rr, bcoef, nbase);
+  int nefc = make_constraint<C>(m, s, lane, rr, bcoef, nbase PROF_PASS);
   jdot<C>(s, lane, nefc, nbase, rr, qvel_i, jqv);                 // aref = -b (J.qvel) - k imp pos
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) rr[ch].aref -= bcoef[ch] * jqv[ch];

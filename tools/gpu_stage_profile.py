@@ -17,7 +17,8 @@ from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
 NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "smooth_forces", "chol_M+solve",
          "solver_init", "hessian: solve only", "linesearch: p0, lo, iterations", "update_constraint", "integrate", "epilogue+store",
          "hessian: weights+compaction", "hessian: sparse rows", "hessian: contacts", "hessian: block exchange", "hessian: cholesky",
-         "linesearch: setup (jdot, M.v, sums)"]
+         "linesearch: setup (jdot, M.v, sums)", "x0 collision: SAT / primitives", "x1 collision: clip slots", "x2 collision: compaction",
+         "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: cost + gauss (rest of update = J^T f)", "x7"]
 n = 8192
 envdef = AirbotPlayBase()
 dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
