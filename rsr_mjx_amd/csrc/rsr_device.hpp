@@ -275,8 +275,6 @@ struct Smem {
   float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction
   float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian (2*NBC-1 used)
-  int rlist[C::NBASE + 4];                             // compacted base rows / contacts with non-zero weight
-  int clist[C::NCON + 4];
   union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
 
@@ -878,10 +876,11 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane 
   // keep penetrating contacts only (result-neutral culling), compact in pair order
   int keep = 0;
   for (int i = 0; i < pts.cnt; ++i) if (pts.dist[i] - incl < 0.0f) keep++;
-  int incl_scan = keep;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl_scan, o); if (lane >= o) incl_scan += v; }
-  int base = incl_scan - keep, total = __shfl(incl_scan, 63);
+  // exclusive prefix sum of keep (0..4) over the lanes from three ballots, one per bit of the count: no cross-lane data moves
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const unsigned long long k0 = __ballot(keep & 1), k1 = __ballot(keep & 2), k2 = __ballot(keep & 4);
+  const int base = __popcll(k0 & below) + 2 * __popcll(k1 & below) + 4 * __popcll(k2 & below);
+  const int total = __popcll(k0) + 2 * __popcll(k1) + 4 * __popcll(k2);
   int w = base;
   for (int i = 0; i < pts.cnt; ++i) {
     if (!(pts.dist[i] - incl < 0.0f)) continue;

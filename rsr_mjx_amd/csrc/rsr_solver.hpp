@@ -146,53 +146,43 @@ __device__ __forceinline__ LSPoint ls_point(int nefc, float alpha, const LSRows<
   return o[0];
 }
 
-// compacts the indices r in [0, n) whose flag is set into list[], padded with `pad` to a multiple of four
-template <int NCH>
-__device__ __forceinline__ int compact_list(int* list, int lane, const bool (&on)[NCH], int pad) {
-  int base = 0;
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    unsigned long long mask = __ballot(on[ch]);
-    if (on[ch]) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = lane + 64 * ch;
-    base += __popcll(mask);
-  }
-  if (lane < 4) list[base + lane] = pad;
-  return base;
-}
-
-// qfrc_constraint = J^T force.  The pyramid forces are folded onto the base rows first
-// (normal: sum of the six edges; direction k: mu_k * (f_k+ - f_k-)), then J_base^T g, four base rows per trip.
+// qfrc_constraint = J^T force.  Friction and limit rows have one +-1 entry: their force goes straight to that dof (one LDS
+// float add per row).  The pyramid forces of a contact are folded onto its base rows (normal: sum of the edges;
+// direction k: mu_k * (f_k+ - f_k-)), then J_base^T g runs over the contact base rows four per trip with addresses that
+// are affine in the trip counter, so the loads of a trip (and of the next) are independent of each other.
 template <class C>
 __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nbase, const float (&force)[C::NCHUNK]) {
-  constexpr int r_con = 0;   // (placeholder to keep the expression below readable)
-  (void)r_con;
+  const int ncon = s.ncon, rcon = nefc - C::NPYR * ncon;     // first contact row (pyramid and base numbering agree below it)
   WSYNC();
 #pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r < nefc) s.rw[r] = force[ch]; }
+  for (int ch = 0; ch < C::NCHUNK; ++ch) { int r = lane + 64 * ch; if (r >= rcon && r < nefc) s.rw[r] = force[ch]; }
+  if (lane < C::NV) s.dgw[lane] = 0.0f;
   WSYNC();
-  const int rcon = nefc - C::NPYR * s.ncon;     // first contact row (pyramid and base numbering agree below it)
-  bool on[C::NCHB];
+  if (lane >= C::NEQ && lane < rcon && force[0] != 0.0f) {
+    const int d = s.sdof[lane];
+    atomicAdd(&s.dgw[d], force[0] * s.x.b.J[lane * C::LD + d]);
+  }
+  constexpr int NCB = (C::NBC * C::NCON + 63) / 64;
 #pragma unroll
-  for (int ch = 0; ch < C::NCHB; ++ch) {
-    int b = lane + 64 * ch;
-    float g = 0.0f;
-    if (b < rcon) g = s.rw[b];
-    else if (b < nbase) {
-      int c = (b - rcon) / C::NBC, k = (b - rcon) - C::NBC * c, r0 = rcon + C::NPYR * c;
+  for (int ch = 0; ch < NCB; ++ch) {
+    int t = lane + 64 * ch;
+    if (t < C::NBC * ncon) {
+      int c = t / C::NBC, k = t - C::NBC * c, r0 = rcon + C::NPYR * c;
+      float g = 0.0f;
       if (k == 0) {
 #pragma unroll
         for (int e = 0; e < C::NPYR; e += 2) g += s.rw[r0 + e] + s.rw[r0 + e + 1];
-      } else g = s.bmu[b] * (s.rw[r0 + 2 * (k - 1)] - s.rw[r0 + 2 * (k - 1) + 1]);
+      } else g = s.bmu[rcon + t] * (s.rw[r0 + 2 * (k - 1)] - s.rw[r0 + 2 * (k - 1) + 1]);
+      s.bval[rcon + t] = g;
     }
-    if (b < nbase) s.bval[b] = g;
-    on[ch] = b < nbase && g != 0.0f;
   }
-  const int n = compact_list<C::NCHB>(s.rlist, lane, on, C::NBASE);
   WSYNC();
   const int col = lane < C::NV ? lane : 0;
-  float acc0 = 0, acc1 = 0;
-  for (int k = 0; k < n; k += 4) {
-    int r0 = s.rlist[k], r1 = s.rlist[k + 1], r2 = s.rlist[k + 2], r3 = s.rlist[k + 3];
+  float acc0 = s.dgw[col], acc1 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < C::NEQ; ++r) acc1 += s.x.b.J[r * C::LD + col] * rdlane(force[0], r);
+  for (int b = rcon; b < nbase; b += 4) {
+    const int r0 = b, r1 = b + 1 < nbase ? b + 1 : C::NBASE, r2 = b + 2 < nbase ? b + 2 : C::NBASE, r3 = b + 3 < nbase ? b + 3 : C::NBASE;
     acc0 += s.x.b.J[r0 * C::LD + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LD + col] * s.bval[r1];
     acc0 += s.x.b.J[r2 * C::LD + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LD + col] * s.bval[r3];
   }
