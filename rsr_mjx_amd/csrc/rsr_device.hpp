@@ -109,7 +109,10 @@ struct Dims {
   static constexpr int NQ = NQ_, NV = NV_, NU = NU_, NB = NB_, NJ = NJ_, NG = NG_, NS = NS_, NP = NP_;
   static constexpr int NEG = NEG_, EG0 = EG0_;   // geoms whose world position the env epilogue reads: env_ids[EG0 .. EG0+NEG)
   static constexpr int NEQ = NEQ_, NF = NF_, NL = NL_, NCON = NCON_, OBS = OBS_, NMET = NMET_;
-  static constexpr int LD = NV_ + 1;                        // padded row stride: conflict-free row and column reads
+  static constexpr int LD = NV_ + 1;                        // padded row stride of M / T: conflict-free row and column reads
+  // Row stride of the Jacobian: a multiple of 4 floats so that a lane fetches its row with ds_read_b128, and an odd number of
+  // quads so that the 16 lanes of a b128 phase (stride LDJ words) fall on distinct bank quads.
+  static constexpr int LDJ = (((NV_ + 3) / 4) % 2 == 1) ? ((NV_ + 3) / 4) * 4 : ((NV_ + 3) / 4 + 1) * 4;
   static constexpr int NPYR = 2 * (CONDIM_ - 1);             // pyramid edges per contact
   static constexpr int NEFC = NEQ_ + NF_ + NL_ + NPYR * NCON_;   // constraint-row capacity (pyramid rows)
   static constexpr int NCHUNK = (NEFC + 63) / 64;           // rows per lane
@@ -242,7 +245,7 @@ struct PhaseA {
 };
 template <class C>
 struct PhaseB {
-  float J[(C::NBASE + 1) * C::LD];                     // base rows; row NBASE is the null row padding row lists
+  alignas(16) float J[(C::NBASE + 1) * C::LDJ];        // base rows (stride LDJ); row NBASE is the null row that pads row groups
 };
 template <class C>
 struct Smem {
@@ -1044,7 +1047,7 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
 template <class C>
 __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
                                int& nbase_out PROF_ARG) {
-  constexpr int LD = C::LD;
+  constexpr int LD = C::LDJ;      // every LD below strides the Jacobian
   // active joint limits, compacted in joint order
   int lim_active = 0;
   if (lane < C::NL) {

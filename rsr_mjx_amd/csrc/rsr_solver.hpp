@@ -24,9 +24,17 @@ __device__ __forceinline__ void jdot(Smem<C>& s, int lane, int nefc, int nbase, 
   for (int ch = 0; ch < C::NCHB; ++ch) {
     if (64 * ch >= nbase) continue;             // wave-uniform
     int b = lane + 64 * ch, bb = b < nbase ? b : C::NBASE;
+    // the lane's whole row in LDJ/4 ds_read_b128, all in flight before the first multiply
+    const float4* row = reinterpret_cast<const float4*>(&s.x.b.J[bb * C::LDJ]);
+    float4 q[C::LDJ / 4];
+#pragma unroll
+    for (int k = 0; k < C::LDJ / 4; ++k) q[k] = row[k];
     float acc = 0;
 #pragma unroll
-    for (int i = 0; i < C::NV; ++i) acc += s.x.b.J[bb * C::LD + i] * vb[i];
+    for (int i = 0; i < C::NV; ++i) {
+      const float4& t = q[i / 4];
+      acc += (i % 4 == 0 ? t.x : (i % 4 == 1 ? t.y : (i % 4 == 2 ? t.z : t.w))) * vb[i];
+    }
     if (b < nbase) s.bval[b] = acc;
   }
   WSYNC();
@@ -160,7 +168,7 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
   WSYNC();
   if (lane >= C::NEQ && lane < rcon && force[0] != 0.0f) {
     const int d = s.sdof[lane];
-    atomicAdd(&s.dgw[d], force[0] * s.x.b.J[lane * C::LD + d]);
+    atomicAdd(&s.dgw[d], force[0] * s.x.b.J[lane * C::LDJ + d]);
   }
   constexpr int NCB = (C::NBC * C::NCON + 63) / 64;
 #pragma unroll
@@ -180,11 +188,11 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
   const int col = lane < C::NV ? lane : 0;
   float acc0 = s.dgw[col], acc1 = 0.0f;
 #pragma unroll
-  for (int r = 0; r < C::NEQ; ++r) acc1 += s.x.b.J[r * C::LD + col] * rdlane(force[0], r);
+  for (int r = 0; r < C::NEQ; ++r) acc1 += s.x.b.J[r * C::LDJ + col] * rdlane(force[0], r);
   for (int b = rcon; b < nbase; b += 4) {
     const int r0 = b, r1 = b + 1 < nbase ? b + 1 : C::NBASE, r2 = b + 2 < nbase ? b + 2 : C::NBASE, r3 = b + 3 < nbase ? b + 3 : C::NBASE;
-    acc0 += s.x.b.J[r0 * C::LD + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LD + col] * s.bval[r1];
-    acc0 += s.x.b.J[r2 * C::LD + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LD + col] * s.bval[r3];
+    acc0 += s.x.b.J[r0 * C::LDJ + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LDJ + col] * s.bval[r1];
+    acc0 += s.x.b.J[r2 * C::LDJ + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LDJ + col] * s.bval[r3];
   }
   return lane < C::NV ? acc0 + acc1 : 0.0f;
 }
@@ -235,14 +243,14 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   if (bi == bj) { h00 += s.dgw[i0]; h11 += s.dgw[i0 + 1]; }
 #pragma unroll
   for (int r = 0; r < C::NEQ; ++r) {
-    const float* Jr = &s.x.b.J[r * C::LD];
+    const float* Jr = &s.x.b.J[r * C::LDJ];
     float w = rdlane(hw[0], r);
     float a0 = Jr[i0] * w, a1 = Jr[i0 + 1] * w, b0 = Jr[j0], b1 = Jr[j0 + 1];
     h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
   }
   PROF(PS_H_SPARSE)
   for (int c = 0; c < ncon; ++c) {
-    const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LD];
+    const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LDJ];
     const float* w = &s.wc[8 * c];
     float ni0 = B[i0], ni1 = B[i0 + 1], nj0 = B[j0], nj1 = B[j0 + 1];
     float u0n = w[0] * nj0, u1n = w[0] * nj1;          // (W b_j)[normal] for the two columns of the block
@@ -250,7 +258,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
 #pragma unroll
     for (int d = 1; d < C::NBC; ++d) {
       float wn = w[d], wd = w[C::NBC - 1 + d];
-      float di0 = B[d * C::LD + i0], di1 = B[d * C::LD + i0 + 1], dj0 = B[d * C::LD + j0], dj1 = B[d * C::LD + j0 + 1];
+      float di0 = B[d * C::LDJ + i0], di1 = B[d * C::LDJ + i0 + 1], dj0 = B[d * C::LDJ + j0], dj1 = B[d * C::LDJ + j0 + 1];
       u0n += wn * dj0; u1n += wn * dj1;
       float u0d = wn * nj0 + wd * dj0, u1d = wn * nj1 + wd * dj1;   // (W b_j)[direction d]
       a00 += di0 * u0d; a01 += di0 * u1d; a10 += di1 * u0d; a11 += di1 * u1d;
@@ -464,10 +472,10 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
       for (int t = lane; t < nefc * C::NV && t < 4300; t += 64) {
         int r = t / C::NV, i = t % C::NV;
         float v;
-        if (r < rcon) v = s.x.b.J[r * C::LD + i];
+        if (r < rcon) v = s.x.b.J[r * C::LDJ + i];
         else {
           int c = (r - rcon) / C::NPYR, e = (r - rcon) % C::NPYR, bn = rcon + C::NBC * c, bk = bn + 1 + (e >> 1);
-          v = s.x.b.J[bn * C::LD + i] + ((e & 1) ? -s.bmu[bk] : s.bmu[bk]) * s.x.b.J[bk * C::LD + i];
+          v = s.x.b.J[bn * C::LDJ + i] + ((e & 1) ? -s.bmu[bk] : s.bmu[bk]) * s.x.b.J[bk * C::LDJ + i];
         }
         dbg[2048 + t] = v;
       }
