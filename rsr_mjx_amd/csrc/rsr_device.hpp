@@ -534,32 +534,52 @@ __device__ __forceinline__ void make_frame(V3 n, V3& a, V3& b, V3& c) {
 
 // choose <=4 of n masked 2-D points with approximately maximal area; see oracle manifold_points
 __device__ __forceinline__ void manifold_points(const float* x, const float* y, unsigned mask, int n, int* idx) {
+  // The (at most 8) points are fetched once, all loads in flight together, and every pass runs over registers with
+  // compile-time indices; the chosen point's coordinates are carried along with its index (a runtime index into the
+  // register copy would send it to scratch memory, and four passes over LDS are 4n dependent round trips).
   const float NEG = -1e6f;
+  float px[8], py[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { px[i] = x[i]; py[i] = y[i]; }      // slots >= n hold stale data: masked by i < n below
   int a = 0, b = 0, c = 0, dd = 0;
+  float xa = 0, ya = 0, xb = 0, yb = 0, xc = 0, yc = 0;
   float best = NEG * 2;
-  for (int i = 0; i < n; ++i) { float v = ((mask >> i) & 1) ? 0.0f : NEG; if (v > best) { best = v; a = i; } }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = ((mask >> i) & 1) ? 0.0f : NEG;
+    if (i < n && v > best) { best = v; a = i; xa = px[i]; ya = py[i]; }
+  }
   best = NEG * 4;
-  for (int i = 0; i < n; ++i) {
-    float dx = x[a] - x[i], dy = y[a] - y[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float dx = xa - px[i], dy = ya - py[i];
     float v = dx * dx + dy * dy + (((mask >> i) & 1) ? 0.0f : NEG);
-    if (v > best) { best = v; b = i; }
+    if (i < n && v > best) { best = v; b = i; xb = px[i]; yb = py[i]; }
   }
-  float abx = -(y[a] - y[b]), aby = (x[a] - x[b]);
+  float abx = -(ya - yb), aby = (xa - xb);
   best = NEG * 4;
-  for (int i = 0; i < n; ++i) {
-    float v = fabsf((x[a] - x[i]) * abx + (y[a] - y[i]) * aby) + (((mask >> i) & 1) ? 0.0f : NEG);
-    if (v > best) { best = v; c = i; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = fabsf((xa - px[i]) * abx + (ya - py[i]) * aby) + (((mask >> i) & 1) ? 0.0f : NEG);
+    if (i < n && v > best) { best = v; c = i; xc = px[i]; yc = py[i]; }
   }
-  float sc = ((x[a] - x[c]) * abx + (y[a] - y[c]) * aby) > 0 ? 1.0f : -1.0f;
+  float sc = ((xa - xc) * abx + (ya - yc) * aby) > 0 ? 1.0f : -1.0f;
   best = 0; dd = c;
-  for (int i = 0; i < n; ++i) {
-    float v = -sc * ((x[a] - x[i]) * abx + (y[a] - y[i]) * aby);
-    if (((mask >> i) & 1) && v > best) { best = v; dd = i; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = -sc * ((xa - px[i]) * abx + (ya - py[i]) * aby);
+    if (i < n && ((mask >> i) & 1) && v > best) { best = v; dd = i; }
   }
   idx[0] = a; idx[1] = b; idx[2] = c; idx[3] = dd;
 }
 
 struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; };
+// append without a runtime array index (a runtime index would put the whole struct in scratch memory)
+__device__ __forceinline__ void cpts_push(CPts& o, float dist, V3 pos) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (o.cnt == k) { o.dist[k] = dist; o.pos[k] = pos; }
+  o.cnt++;
+}
 
 // A pair whose narrow phase found penetration and now needs LDS scratch for its manifold (24 floats for
 // plane-box vertex supports, 48 for the two ping-pong polygons of box-box clipping).  Everything the second
@@ -604,7 +624,7 @@ __device__ void plane_box_clip(const ClipJob& job, float* scr, CPts& out) {
     for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
     if (dup || !((mask >> idx[i]) & 1)) continue;
     float dist = -sup[idx[i]];
-    out.dist[out.cnt] = dist; out.pos[out.cnt] = box_vertex(job.bm, job.bp, job.size, idx[i]) - job.nref * (0.5f * dist); out.cnt++;
+    cpts_push(out, dist, box_vertex(job.bm, job.bp, job.size, idx[i]) - job.nref * (0.5f * dist));
   }
 }
 
@@ -755,9 +775,7 @@ __device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
     for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
     if (dup || !((mask >> idx[i]) & 1)) continue;
     float x = P[idx[i]], y = P[8 + idx[i]], dep = P[16 + idx[i]];
-    out.dist[out.cnt] = -dep;
-    out.pos[out.cnt] = job.o + job.axu * x + job.axv * y - job.nref * (0.5f * dep);
-    out.cnt++;
+    cpts_push(out, -dep, job.o + job.axu * x + job.axv * y - job.nref * (0.5f * dep));
   }
 }
 
@@ -878,15 +896,17 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane 
   PROF(PS_X1)
   // keep penetrating contacts only (result-neutral culling), compact in pair order
   int keep = 0;
-  for (int i = 0; i < pts.cnt; ++i) if (pts.dist[i] - incl < 0.0f) keep++;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (i < pts.cnt && pts.dist[i] - incl < 0.0f) keep++;
   // exclusive prefix sum of keep (0..4) over the lanes from three ballots, one per bit of the count: no cross-lane data moves
   const unsigned long long below = (1ull << lane) - 1ull;
   const unsigned long long k0 = __ballot(keep & 1), k1 = __ballot(keep & 2), k2 = __ballot(keep & 4);
   const int base = __popcll(k0 & below) + 2 * __popcll(k1 & below) + 4 * __popcll(k2 & below);
   const int total = __popcll(k0) + 2 * __popcll(k1) + 4 * __popcll(k2);
   int w = base;
-  for (int i = 0; i < pts.cnt; ++i) {
-    if (!(pts.dist[i] - incl < 0.0f)) continue;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!(i < pts.cnt && pts.dist[i] - incl < 0.0f)) continue;
     if (w < C::NCON) {
       s.cdist[w] = pts.dist[i]; st3(&s.cpos[3 * w], pts.pos[i]); st3(&s.cnrm[3 * w], pts.n); s.cpair[w] = lane;
     }

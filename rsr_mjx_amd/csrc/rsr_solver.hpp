@@ -113,14 +113,18 @@ template <class C, int NPT>
 __device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], const LSRows<C>& w, float g0, float g1, float g2,
                                         LSPoint (&out)[NPT]) {
   float q[NPT][3];
+  // (copies first: a ?: between struct members is an lvalue select, which would pin the struct in scratch memory)
+  const float ja0 = w.ja[0], v0 = w.v[0], tlo = w.tlo, thi = w.thi, c0m = w.c0m, c0p = w.c0p, c1m = w.c1m, c1p = w.c1p;
+  const float b00 = w.b0[0], b10 = w.b1[0], b20 = w.b2[0];
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
     // chunk 0: three pieces
-    float x = w.ja[0] + alpha[p] * w.v[0];
-    bool lo = x <= -w.tlo, hi = x >= w.thi;
-    q[p][0] = lo ? w.c0m : (hi ? w.c0p : w.b0[0]);
-    q[p][1] = lo ? w.c1m : (hi ? w.c1p : w.b1[0]);
-    q[p][2] = (lo || hi) ? 0.0f : w.b2[0];
+    float x = ja0 + alpha[p] * v0;
+    bool lo = x <= -tlo, hi = x >= thi;
+    float u0 = hi ? c0p : b00, u1 = hi ? c1p : b10;
+    q[p][0] = lo ? c0m : u0;
+    q[p][1] = lo ? c1m : u1;
+    q[p][2] = (lo || hi) ? 0.0f : b20;
   }
 #pragma unroll
   for (int ch = 1; ch < C::NCHUNK; ++ch) {
