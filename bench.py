@@ -27,6 +27,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_BYTES_S = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 BYTES_PER_ENV_STEP_DR = 1220       # algorithmic bytes per env-step, Airbot cube with DR
 BYTES_PER_ENV_STEP = 728           # ... without DR
+VALU_PEAK_WAVE_INST_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md constants)
+
+
+def pmc_profile(workload: str, n: int, dr_on: bool):
+    """HBM traffic and instruction counts per launch from the committed rocprofv3 PMC passes (profiles/round1_final_pmc_*.csv,
+    collected by tools/gpu_final_profile.sh on this very command line).  PMC cannot be read from inside the process, so the
+    numbers apply only to the configuration they were measured on (headline cube, 8192 envs, DR on); otherwise None."""
+    if workload != "cube" or n != 8192 or not dr_on:
+        return None
+    import csv
+    vals = {}
+    for tag in ("fetch", "write", "inst"):
+        path = os.path.join(ROOT, "profiles", f"round1_final_pmc_{tag}.csv")
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if "step_kernel" in row["kernel"]:
+                vals[row["counter"]] = float(row["avg_per_dispatch"])
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return vals
 
 
 def cpu_baseline(blob: bytes, dr, seconds: float = 12.0, nu: int = 5, act_std: float = 1.0):
@@ -145,6 +166,8 @@ def main():
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()
+        pmc = pmc_profile(args.workload, n, not args.no_dr)
+        traffic = None if pmc is None else (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0      # rocprofv3 reports KiB
         out = {
             "metric": "env-steps/sec at num_envs=8192, Airbot cube" if args.workload == "cube" else f"env-steps/sec, {wl_name}",
             "value": env_steps / elapsed,
@@ -171,10 +194,20 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_BYTES_S, "traffic": None,
+                "frac": achieved / HBM_PEAK_BYTES_S, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per * n, "avg_launch_ms": avg_launch_s * 1e3,
-                "note": "state stays on-chip for the whole step, so the path is VALU/LDS-latency bound, not HBM bound "
-                        "(SURVEY.md 8d); the fraction is reported because the metric names it",
+                "traffic_detail": None if pmc is None else {
+                    "fetch_bytes": pmc["FETCH_SIZE"] * 1024.0, "write_bytes": pmc["WRITE_SIZE"] * 1024.0,
+                    "source": "profiles/round1_final_pmc_fetch.csv, _write.csv (separate rocprofv3 --pmc passes, per launch; "
+                              "dword-per-lane accesses are uncalibrated on gfx950, MI355X_MICROARCH.md HBM section); writes above "
+                              "the record size are register spills to scratch memory (DESIGN.md 4)"},
+                "valu": None if pmc is None or "SQ_INSTS_VALU" not in pmc else {
+                    "wave_instructions_per_env_step": pmc["SQ_INSTS_VALU"] / n,
+                    "achieved_wave_inst_per_s": pmc["SQ_INSTS_VALU"] / avg_launch_s,
+                    "peak_wave_inst_per_s": VALU_PEAK_WAVE_INST_S,
+                    "frac": pmc["SQ_INSTS_VALU"] / avg_launch_s / VALU_PEAK_WAVE_INST_S},
+                "note": "state stays on-chip for the whole step, so the path is VALU-issue / LDS-latency bound, not HBM bound "
+                        "(SURVEY.md 8d); the HBM fraction is reported because the metric names it, the VALU fraction beside it",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
