@@ -276,7 +276,11 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   }
   WSYNC();
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) a[j] = (lane < C::NV && j <= lane) ? s.T[lane * C::LD + j] : 0.0f;
+  for (int j = 0; j < C::NV; ++j) {
+    // unconditional in-bounds load, then a select: a load under a per-j condition is a separate exec-mask region each
+    const float t = s.T[(lane < C::NV ? lane : 0) * C::LD + j];
+    a[j] = (lane < C::NV && j <= lane) ? t : 0.0f;
+  }
   WSYNC();
   PROF(PS_H_XCHG)
   const float dinv = chol_factor<C>(a, lt, s.T, lane);
