@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2", "go2rough"],
                     help="cube = BASELINE headline (configs[1] family); tshape / go2 / go2rough = configs[2] / [3] / [4] families")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the bounded CPU-oracle sample")
     args = ap.parse_args()
 
     import torch
@@ -211,7 +212,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env.blob, dr, nu=nu, act_std=act_std)
+            out["cpu_baseline"] = cpu_baseline(env.blob, dr, seconds=args.cpu_seconds, nu=nu, act_std=act_std)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -268,3 +268,31 @@ def test_full_size_properties(setup):
     env = setup["envdef"].batched(8)
     steps = a[:, (env.view("info_steps").data_ptr() - env.record.data_ptr()) // 4]
     assert float(steps.min()) == float(steps.max()) == 10.0       # 30 steps = 3 truncated episodes of 10
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads, the roofline and cpu_baseline objects included."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-seconds", "1.0"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "env-steps/s"
+    assert "workload" in d["config"] and "model" not in d["config"] and "num_envs=8192" in d["config"]["workload"]
+    assert abs(d["value"] - 8192 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    assert abs(r["achieved"] * 1e9 - 1220 * 8192 / (r["avg_launch_ms"] * 1e-3)) / (r["achieved"] * 1e9) < 1e-6
+    assert r["avg_launch_ms"] <= d["ms_per_step"] * 1.05                      # HIP-event kernel time vs wall time per step
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and "oracle" in c["sample"]
+    assert d["value"] > 20 * c["value"]
