@@ -329,6 +329,25 @@ def wrap(env: AirbotPlayBase, num_envs: int, episode_length: int = 1000, action_
     return env.batched(num_envs, episode_length=episode_length, auto_reset=True, randomization=dr)
 
 
+def wrap_sub_batches(env, num_envs: int, parts: int, episode_length: int = 1000, action_repeat: int = 1,
+                     randomization_fn: Optional[Callable[[CompiledModel], Dict[str, Any]]] = None):
+    """`wrap`, but as `parts` independent BatchedEnvs over contiguous blocks of the env index, for consumers that work per
+    sub-batch on separate HIP streams (rollout.generate_unroll_pipelined, bench.py `sub_batched`): one sub-batch's launch
+    tail is then hidden behind the other's next launch.  Env i is the same env as in `wrap`: keys and
+    randomised leaves are sliced by index.  Works for every env definition with a `batched` method (Airbot, Go2)."""
+    if action_repeat != 1:
+        raise NotImplementedError("action_repeat != 1")
+    if num_envs % parts:
+        raise ValueError("num_envs must be a multiple of parts")
+    m = num_envs // parts
+    dr = randomization_fn(env.sys) if randomization_fn is not None else None
+    out = []
+    for k in range(parts):
+        sub = None if dr is None else {f: v[k * m:(k + 1) * m] for f, v in dr.items()}
+        out.append(env.batched(m, episode_length=episode_length, auto_reset=True, randomization=sub))
+    return out
+
+
 def domain_randomize(sys: CompiledModel, rng: np.ndarray) -> Dict[str, np.ndarray]:
     """reference ppo_train/airbot_training/domain_randomize.py:26-91: six uniforms per env scale table / cube /
     finger friction, cube mass, arm dof damping and frictionloss.  rng: uint32 [N, 2]."""

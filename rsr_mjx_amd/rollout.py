@@ -94,6 +94,69 @@ def generate_unroll(env, env_state, policy: Policy, key: np.ndarray, unroll_leng
     return state, data
 
 
+def generate_unroll_pipelined(envs: Sequence[Any], env_states: Sequence[Any], policy: Policy, key: np.ndarray,
+                              unroll_length: int, extra_fields: Sequence[str] = ()):
+    """`generate_unroll` over several independent sub-batches (airbot.wrap_sub_batches), each on its own HIP stream:
+    policy and env step of sub-batch k are enqueued on stream k, so sub-batch A's policy / launch tail overlaps sub-batch
+    B's env step.  Step t of every sub-batch uses the same key of the chain (the reference splits one key per step for
+    the whole batch); a policy that draws noise from it should fold in the sub-batch's env offset.  Returns
+    (final_states, Transition) with the sub-batches concatenated back along the env axis, env i in the same place as in
+    the lock-step unroll."""
+    import torch
+    parts = len(envs)
+    streams = [torch.cuda.Stream() if torch.cuda.is_available() else None for _ in range(parts)]
+    main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    bufs = [dict() for _ in range(parts)]
+    states = list(env_states)
+
+    def put(k, name, t, value):
+        b = bufs[k]
+        if name not in b:
+            b[name] = torch.empty((unroll_length,) + tuple(value.shape), dtype=value.dtype, device=value.device)
+        b[name][t].copy_(value)
+
+    cur = np.asarray(key, dtype=np.uint32)
+    for st in streams:
+        if st is not None:
+            st.wait_stream(main)
+    for t in range(unroll_length):
+        ks = prng.split(cur, 2)
+        step_key, cur = ks[0], ks[1]
+        for k in range(parts):
+            ctx = torch.cuda.stream(streams[k]) if streams[k] is not None else _NullCtx()
+            with ctx:
+                state = states[k]
+                put(k, "observation", t, _obs(state))
+                actions, policy_extras = policy(bufs[k]["observation"][t], step_key)
+                state = envs[k].step(state, actions)
+                put(k, "action", t, actions); put(k, "reward", t, state.reward); put(k, "done", t, state.done)
+                put(k, "next_observation", t, _obs(state))
+                for x in extra_fields:
+                    put(k, "state/" + x, t, state.info[x])
+                for name, v in policy_extras.items():
+                    put(k, "policy/" + name, t, v)
+                states[k] = state
+    for st in streams:
+        if st is not None:
+            main.wait_stream(st)
+    cat = lambda name: torch.cat([b[name] for b in bufs], dim=1)
+    names = list(bufs[0])
+    data = Transition(
+        observation=cat("observation"), action=cat("action"), reward=cat("reward"), discount=1.0 - cat("done"),
+        next_observation=cat("next_observation"),
+        extras={"policy_extras": {n[7:]: cat(n) for n in names if n.startswith("policy/")},
+                "state_extras": {n[6:]: cat(n) for n in names if n.startswith("state/")}})
+    return states, data
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 @dataclass
 class EvalMetrics:
     """brax.envs.wrappers.training.EvalMetrics."""
