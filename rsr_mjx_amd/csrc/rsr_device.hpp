@@ -233,7 +233,7 @@ __device__ __forceinline__ unsigned long long prof_now() {
 //   phase A (kinematics .. collision): body/geom frames, spatial inertias, velocity-stage scratch, clip slots
 //   phase B (constraint rows .. solve): the constraint Jacobian
 // What both phases (or the env epilogue) need stays outside the union.
-constexpr int NSLOT = 16;                              // clip-scratch slots handed out to penetrating pairs
+constexpr int NSLOT = 16;                              // clip-scratch slots handed out to penetrating pairs (models with box pairs)
 template <class C>
 struct PhaseA {
   float xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
@@ -241,7 +241,7 @@ struct PhaseA {
   float gpos[C::NG * 3], gmat[C::NG * 9];
   float cinert[C::NB * 10], crb[C::NB * 10];
   float cvel[C::NB * 6], cdofdot[C::NV * 6], cfrc[C::NB * 6], cfrcsum[C::NB * 6];
-  float clip[NSLOT * 48];
+  float clip[(C::CONDIM == 3 ? 1 : NSLOT) * 48];     // condim-3 models here are sphere-only (Go2): no clipping, one dummy slot
 };
 template <class C>
 struct PhaseB {

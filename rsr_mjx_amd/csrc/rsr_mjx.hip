@@ -631,7 +631,10 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
 
 // ---------------------------------------------------------------- Go2 step kernel (joystick.py:204-280 + wrappers)
 template <class C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
+#ifndef RSR_GO2_WAVES_PER_EU
+#define RSR_GO2_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_GO2_WAVES_PER_EU, RSR_GO2_WAVES_PER_EU)))
 void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
