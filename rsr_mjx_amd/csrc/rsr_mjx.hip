@@ -21,7 +21,7 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
                      /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true>;
-using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
+using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
 enum { ID_CUBE = 0, ID_TARGET = 1, ID_SITE = 2, ID_BOXQ = 3, ID_SITEQ = 4, ID_FINGERQ = 5, ID_JOINTQ = 6 };
