@@ -20,19 +20,25 @@ NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "
          "linesearch: setup (jdot, M.v, sums)", "x0 collision: SAT / primitives", "x1 collision: clip slots", "x2 collision: compaction",
          "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: cost + gauss (rest of update = J^T f)", "x7"]
 n = 8192
-envdef = AirbotPlayBase()
-dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
-env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
+if "--go2" in sys.argv:
+    from rsr_mjx_amd.envs import go2
+    env = go2.load("Go2JoystickFlatTerrain").batched(n, episode_length=1000, auto_reset=True)
+    nu, astd = 12, 0.3
+else:
+    envdef = AirbotPlayBase()
+    dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
+    env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
+    nu, astd = 5, 1.0
 s = env.reset(prng.split(prng.PRNGKey(0), n))
 dbg = env.enable_debug(True)
 tot = np.zeros(len(NAMES))
 for t in range(40):
-    env.step(s, torch.clamp(torch.randn(n, 5, device="cuda"), -1, 1))
+    env.step(s, torch.clamp(torch.randn(n, nu, device="cuda") * astd, -1, 1))
     if t >= 10:
         torch.cuda.synchronize()
         tot += dbg[:, 7200:7200 + len(NAMES)].double().mean(dim=0).cpu().numpy()
 tot /= 30
-print(f"mean cycles per env-step (wave lifetime, 4 substeps): {tot.sum():.0f}")
+print(f"mean cycles per env-step (wave lifetime, all substeps): {tot.sum():.0f}")
 for nm, v in zip(NAMES, tot):
     print(f"  {nm:24s} {v:10.0f}  {100 * v / tot.sum():5.1f} %")
 print("stats mean [niter ls ncon drop]", env.view("stats").float().mean(dim=0).tolist())
