@@ -6,4 +6,4 @@ TAG=$1; shift
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$TAG -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline ${BENCH_ARGS} > $O/pmc_$TAG.json 2> $O/pmc_$TAG.err
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_$TAG -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 ${BENCH_ARGS} > $O/pmc_$TAG.json 2> $O/pmc_$TAG.err
