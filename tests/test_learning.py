@@ -1,0 +1,199 @@
+"""rsr_mjx_amd/learning (RSR distribution loss, GAE, PPO / SAC losses) against the numpy fp64 restatement in
+oracle/losses_np.py and against closed-form properties."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import losses_np as O  # noqa: E402
+from rsr_mjx_amd import prng  # noqa: E402
+from rsr_mjx_amd.learning import ppo_losses as P, rsr_loss as R, sac_losses as S  # noqa: E402
+from rsr_mjx_amd.rollout import Transition  # noqa: E402
+
+T64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
+
+
+def test_kde_kl_wasserstein_match_the_restatement():
+    rng = np.random.default_rng(0)
+    data, grid = rng.normal(size=(50, 7)), rng.uniform(-3, 3, size=(12, 7))
+    for h in (0.1, 0.5, 2.0):
+        p = R.evaluate_kde(T64(data), T64(grid), h).numpy()
+        np.testing.assert_allclose(p, O.evaluate_kde(data, grid, h), rtol=1e-9, atol=1e-300)
+        assert abs(p.sum() - 1) < 1e-12 and (p >= 0).all()
+    p, q = O.evaluate_kde(data, grid, 1.0), O.evaluate_kde(data * 0.5 + 0.3, grid, 1.0)
+    assert R.kl_divergence(T64(p), T64(q)).item() == pytest.approx(O.kl_divergence(p, q), rel=1e-12) and O.kl_divergence(p, q) > 0
+    assert R.kl_divergence(T64(p), T64(p)).item() == pytest.approx(0, abs=1e-12)
+    assert R.wasserstein_distance(T64(p), T64(q)).item() == pytest.approx(O.wasserstein_distance(p, q), rel=1e-12)
+    assert R.wasserstein_distance(T64(p), T64(p)).item() == 0
+    # the grid is jax.random.uniform(PRNGKey(seed), (n, D), -3, 3) on the threefry restatement
+    g = R.make_grid(10, 5, seed=0).numpy()
+    np.testing.assert_array_equal(g, prng.uniform(prng.PRNGKey(0), (10, 5), -3.0, 3.0))
+    assert g.min() >= -3 and g.max() < 3
+
+
+def test_rsr_loss_value_and_policy_gradient():
+    rng = np.random.default_rng(1)
+    D_o, D_a, n = 4, 2, 40
+    W = D_o + D_a + D_o
+    real, prev, cur = (T64(rng.normal(size=(n, W)) * s + m) for s, m in ((1.0, 0.0), (1.2, 0.3), (1.1, 0.1)))
+    data = R.build_rsr_data(real, prev, cur, num_samples=16, bandwidth=1.5, seed=3)
+    grid = data.grid.double()
+    data = data._replace(grid=grid, reference_density=R.evaluate_kde(cur, grid, 1.5),
+                         divergence=R.kl_divergence(R.evaluate_kde(real, grid, 1.5), R.evaluate_kde(prev, grid, 1.5)))
+    obs, nobs = T64(rng.normal(size=(3, 5, D_o))), T64(rng.normal(size=(3, 5, D_o)))
+    act = T64(rng.uniform(-1, 1, size=(3, 5, D_a))).requires_grad_(True)
+    loss, dist = R.compute_rsr_loss(obs, act, nobs, data, loss_scale=0.7)
+    want, wdist = O.compute_rsr_loss(obs.numpy(), act.detach().numpy(), nobs.numpy(), data.divergence.item(), data.reference_density.numpy(),
+                                     cur.numpy(), grid.numpy(), 1.5, 0.7)
+    assert loss.item() == pytest.approx(want, rel=1e-9) and dist.item() == pytest.approx(wdist, rel=1e-9) and dist.item() > 0
+    loss.backward()
+    g = act.grad.numpy()
+    assert np.abs(g).max() > 0                                      # the term carries a policy gradient (rsr_loss.py docstring)
+    a0 = act.detach().numpy()
+    for idx in ((0, 0, 0), (2, 4, 1)):
+        e = np.zeros_like(a0); e[idx] = 1e-6
+        fd = (O.compute_rsr_loss(obs.numpy(), a0 + e, nobs.numpy(), data.divergence.item(), data.reference_density.numpy(), cur.numpy(), grid.numpy(), 1.5, 0.7)[0]
+              - O.compute_rsr_loss(obs.numpy(), a0 - e, nobs.numpy(), data.divergence.item(), data.reference_density.numpy(), cur.numpy(), grid.numpy(), 1.5, 0.7)[0]) / 2e-6
+        assert g[idx] == pytest.approx(fd, rel=1e-4, abs=1e-10)
+    z, zd = R.compute_rsr_loss(obs, act, nobs, None)
+    assert z.item() == 0 and zd.item() == 0 and R.compute_rsr_loss(obs, act, nobs, data, loss_scale=0.0)[0].item() == 0
+    legacy = (data.divergence, data.reference_density[:10], cur)      # legacy 3-tuple: grid of reference_density.shape[0] points, bandwidth 0.1
+    assert R._as_rsr_data(legacy).grid.shape == (10, W) and R._as_rsr_data(legacy).bandwidth == 0.1
+    with pytest.raises(ValueError):
+        R.compute_rsr_loss(obs[..., :3], act, nobs, data)
+    with pytest.raises(ValueError):
+        R.build_rsr_data(real, prev[:-1], cur)
+
+
+def test_gae_matches_restatement_and_closed_forms():
+    rng = np.random.default_rng(2)
+    T, B = 9, 5
+    trunc = (rng.uniform(size=(T, B)) < 0.15).astype(np.float64)
+    term = (rng.uniform(size=(T, B)) < 0.1).astype(np.float64) * (1 - trunc)
+    rew, val, boot = rng.normal(size=(T, B)), rng.normal(size=(T, B)), rng.normal(size=B)
+    vs, adv = P.compute_gae(T64(trunc), T64(term), T64(rew), T64(val), T64(boot), 0.95, 0.9)
+    wvs, wadv = O.compute_gae(trunc, term, rew, val, boot, 0.95, 0.9)
+    np.testing.assert_allclose(vs.numpy(), wvs, rtol=1e-12); np.testing.assert_allclose(adv.numpy(), wadv, rtol=1e-12)
+    assert not vs.requires_grad and not adv.requires_grad
+    # lambda = 1, no truncation / termination: vs = discounted return to go + bootstrap
+    z = np.zeros((T, B))
+    vs1, _ = P.compute_gae(T64(z), T64(z), T64(rew), T64(val), T64(boot), 1.0, 0.9)
+    ret = boot.copy(); want = np.zeros((T, B))
+    for t in reversed(range(T)):
+        ret = rew[t] + 0.9 * ret; want[t] = ret
+    np.testing.assert_allclose(vs1.numpy(), want, rtol=1e-12)
+    # lambda = 0: one-step TD target
+    vs0, adv0 = P.compute_gae(T64(z), T64(z), T64(rew), T64(val), T64(boot), 0.0, 0.9)
+    vtp1 = np.concatenate([val[1:], boot[None]])
+    np.testing.assert_allclose(vs0.numpy(), rew + 0.9 * vtp1, rtol=1e-12)
+
+
+def _transition(rng, B, T, Do, A):
+    f = lambda *s: T64(rng.normal(size=s))
+    trunc = T64((rng.uniform(size=(B, T)) < 0.1).astype(np.float64))
+    done = torch.maximum(trunc, T64((rng.uniform(size=(B, T)) < 0.1).astype(np.float64)))
+    return Transition(observation=f(B, T, Do), action=torch.tanh(f(B, T, A)), reward=f(B, T), discount=1 - done, next_observation=f(B, T, Do),
+                      extras={"state_extras": {"truncation": trunc}, "policy_extras": {"raw_action": f(B, T, A), "log_prob": f(B, T) * 0.1 - 2.0}})
+
+
+def test_ppo_loss_matches_restatement():
+    rng = np.random.default_rng(3)
+    B, T, Do, A = 6, 8, 5, 3
+    data = _transition(rng, B, T, Do, A)
+    Wp, Wv = T64(rng.normal(size=(Do, 2 * A)) * 0.3).requires_grad_(True), T64(rng.normal(size=(Do,)) * 0.3).requires_grad_(True)
+    policy, value = (lambda o: o @ Wp), (lambda o: o @ Wv)
+    noise = T64(rng.normal(size=(T, B, A)))
+    total, m = P.compute_ppo_loss(policy, value, data, noise, past_data=None)
+    sw = lambda x: x.transpose(0, 1).detach().numpy()
+    obs = sw(data.observation)
+    want = O.ppo_loss(obs @ Wp.detach().numpy(), obs @ Wv.detach().numpy(), sw(data.next_observation)[-1] @ Wv.detach().numpy(), sw(data.reward),
+                      sw(data.discount), sw(data.extras["state_extras"]["truncation"]), sw(data.extras["policy_extras"]["raw_action"]),
+                      sw(data.extras["policy_extras"]["log_prob"]), noise.numpy(), 0.0)
+    assert total.item() == pytest.approx(want[0], rel=1e-10) and m["policy_loss"].item() == pytest.approx(want[1], rel=1e-10)
+    assert m["v_loss"].item() == pytest.approx(want[2], rel=1e-10) and m["entropy_loss"].item() == pytest.approx(want[3], rel=1e-10)
+    assert m["sim2real_loss"].item() == 0
+    total.backward()
+    assert Wp.grad.abs().max() > 0 and Wv.grad.abs().max() > 0
+    # with RSR data the sim2real term is added and differentiable through the policy's MODE action
+    W = Do + A + Do
+    ref = T64(rng.normal(size=(30, W)))
+    rd = R.build_rsr_data(ref, ref * 1.3 + 0.2, ref * 0.9, num_samples=12, bandwidth=2.0)
+    rd = rd._replace(grid=rd.grid.double(), reference_density=R.evaluate_kde(ref * 0.9, rd.grid.double(), 2.0), divergence=rd.divergence.double())
+    Wp.grad = None
+    total2, m2 = P.compute_ppo_loss(policy, value, data, noise, past_data=rd, rsr_loss_scale=2.0)
+    assert m2["sim2real_loss"].item() > 0 and total2.item() == pytest.approx(m2["task_loss"].item() + m2["sim2real_loss"].item(), rel=1e-12)
+    assert m2["task_loss"].item() == pytest.approx(total.item(), rel=1e-12)
+    g = torch.autograd.grad(m2["sim2real_loss"], Wp)[0]
+    assert g[:, :A].abs().max() > 0 and g[:, A:].abs().max() == 0     # mode = tanh(loc): no gradient into the scale half
+
+
+def test_tanh_normal_distribution_helpers():
+    rng = np.random.default_rng(4)
+    logits, raw, noise = rng.normal(size=(7, 6)), rng.normal(size=(7, 3)), rng.normal(size=(7, 3))
+    np.testing.assert_allclose(P.tanh_normal_log_prob(T64(logits), T64(raw)).numpy(), O.log_prob(logits, raw), rtol=1e-12)
+    np.testing.assert_allclose(P.tanh_normal_entropy(T64(logits), T64(noise)).numpy(), O.entropy(logits, noise), rtol=1e-12)
+    # log_prob integrates to one over the squashed action (1-D, numerical quadrature in raw space)
+    lg = np.array([[0.3, -0.2]])
+    xs = np.linspace(-12, 12, 200001)
+    dens = np.exp(O.log_prob(np.repeat(lg, xs.size, 0), xs[:, None]) + O.log_det_tanh(xs))    # back to the raw-space density
+    assert np.trapezoid(dens, xs) == pytest.approx(1.0, abs=1e-6)
+    assert P.tanh_normal_mode(T64(lg)).item() == pytest.approx(np.tanh(0.3))
+
+
+def test_sac_losses_shapes_and_rsr_term():
+    rng = np.random.default_rng(5)
+    B, Do, A = 16, 5, 2
+    f = lambda *s: T64(rng.normal(size=s))
+    tr = Transition(observation=f(B, Do), action=torch.tanh(f(B, A)), reward=f(B), discount=T64((rng.uniform(size=B) < 0.9).astype(np.float64)),
+                    next_observation=f(B, Do), extras={"state_extras": {"truncation": T64(np.zeros(B))}})
+    Wp = f(Do, 2 * A).requires_grad_(True); Wq = f(Do + A, 2).requires_grad_(True)
+    policy = lambda o: o @ Wp
+    q = lambda o, a: torch.cat([o, a], -1) @ Wq
+    alpha_loss, critic_loss, actor_loss = S.make_losses(policy, q, reward_scaling=1.0, discounting=0.99, action_size=A)
+    la = T64(0.0).requires_grad_(True)
+    noise = f(B, A)
+    al = alpha_loss(la, tr, noise); al.backward()
+    # d/dlog_alpha [ exp(log_alpha) * c ] = mean(c) at log_alpha = 0
+    logits = (tr.observation @ Wp).detach().numpy()
+    loc, scale = O.tanh_normal(logits)
+    lp = O.log_prob(logits, loc + scale * noise.numpy())
+    assert la.grad.item() == pytest.approx(np.mean(-lp + 0.5 * A), rel=1e-10)
+    cl = critic_loss(q, q, torch.tensor(0.2, dtype=torch.float64), tr, noise)
+    assert cl.item() > 0 and torch.autograd.grad(cl, Wq)[0].abs().max() > 0
+    a0 = actor_loss(q, torch.tensor(0.2, dtype=torch.float64), tr, noise)
+    ref = T64(rng.normal(size=(20, Do + A + Do)))
+    rd = R.build_rsr_data(ref, ref + 0.5, ref * 1.1, num_samples=8, bandwidth=2.0)
+    rd = rd._replace(grid=rd.grid.double(), reference_density=R.evaluate_kde(ref * 1.1, rd.grid.double(), 2.0), divergence=rd.divergence.double())
+    _, _, actor_rsr = S.make_losses(policy, q, 1.0, 0.99, A, past_data=rd, rsr_loss_scale=3.0)
+    a1 = actor_rsr(q, torch.tensor(0.2, dtype=torch.float64), tr, noise)
+    extra = R.compute_rsr_loss(tr.observation, torch.tanh(T64(loc + scale * noise.numpy())), tr.next_observation, rd, loss_scale=3.0)[0]
+    assert a1.item() == pytest.approx(a0.item() + extra.item(), rel=1e-10) and extra.item() > 0
+
+
+@pytest.mark.gpu
+def test_losses_on_the_gpu_match_fp64_host():
+    """The same PPO + RSR loss on torch-ROCm fp32 tensors (GEMM-form KDE on the device) and on fp64 host tensors."""
+    rng = np.random.default_rng(6)
+    B, T, Do, A = 64, 20, 23, 5
+    data = _transition(rng, B, T, Do, A)
+    Wp, Wv = T64(rng.normal(size=(Do, 2 * A)) * 0.2), T64(rng.normal(size=(Do,)) * 0.2)
+    noise = T64(rng.normal(size=(T, B, A)))
+    ref = T64(rng.normal(size=(256, Do + A + Do)))
+    def run(dev, dt):
+        c = lambda x: x.to(dev, dt)
+        d = Transition(c(data.observation), c(data.action), c(data.reward), c(data.discount), c(data.next_observation),
+                       {"state_extras": {k: c(v) for k, v in data.extras["state_extras"].items()},
+                        "policy_extras": {k: c(v) for k, v in data.extras["policy_extras"].items()}})
+        rd = R.build_rsr_data(c(ref), c(ref * 1.2 + 0.1), c(ref * 0.9), num_samples=10, bandwidth=3.0)
+        wp, wv = c(Wp).detach().clone().requires_grad_(True), c(Wv).detach().clone()
+        total, m = P.compute_ppo_loss(lambda o: o @ wp, lambda o: o @ wv, d, c(noise), past_data=rd, rsr_loss_scale=1.0)
+        total.backward()
+        return total.item(), m["sim2real_loss"].item(), wp.grad.double().cpu().numpy()
+    t64, s64, g64 = run("cpu", torch.float64)
+    t32, s32, g32 = run("cuda", torch.float32)
+    assert t32 == pytest.approx(t64, rel=2e-4) and s32 == pytest.approx(s64, rel=2e-3, abs=1e-6) and s64 > 0
+    np.testing.assert_allclose(g32, g64, rtol=5e-3, atol=5e-4 * np.abs(g64).max())
