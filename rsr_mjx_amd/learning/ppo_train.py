@@ -1,0 +1,190 @@
+"""PPO training loop with the RSR term on the batched stepper (torch-ROCm): the counterpart of reference RSR/train.py:76-503
+(`train(environment, num_timesteps, episode_length, past_data, ...)`), itself Brax's PPO trainer with `past_data` and
+`rsr_loss_scale` threaded into the loss.
+
+Same schedule as the reference: every training step gathers `batch_size * num_minibatches // num_envs` unrolls of
+`unroll_length` steps (train.py:310-324), folds the new observations into the running normaliser (:332-336), then runs
+`num_updates_per_batch` passes of `num_minibatches` Adam steps over the shuffled batch (:262-300).  Networks follow
+brax.training.agents.ppo.networks.make_ppo_networks defaults: policy MLP (32,)*4 -> 2*action_size, value MLP (256,)*5 -> 1,
+swish activations, NormalTanh action distribution.  What differs: the scans are host loops over torch modules, sampling
+noise comes from a torch generator seeded from the jax-style key (not bit-compatible with jax.random.normal), one GPU per
+process (the reference pmaps over local devices).
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import prng
+from ..rollout import Evaluator, Transition, generate_unroll
+from . import ppo_losses
+
+
+class RunningStatistics:
+    """brax.training.acme.running_statistics: count / mean / summed_variance with the batched Welford update, std clipped
+    to [1e-6, 1e6]."""
+
+    def __init__(self, size: int, device=None):
+        import torch
+        self.count = torch.zeros((), dtype=torch.float32, device=device)
+        self.mean = torch.zeros(size, dtype=torch.float32, device=device)
+        self.summed_variance = torch.zeros(size, dtype=torch.float32, device=device)
+        self.std = torch.ones(size, dtype=torch.float32, device=device)
+
+    def update(self, batch) -> None:
+        import torch
+        x = batch.reshape(-1, batch.shape[-1]).to(torch.float32)
+        n = x.shape[0]
+        self.count = self.count + n
+        diff_old = x - self.mean
+        self.mean = self.mean + diff_old.sum(0) / self.count
+        self.summed_variance = self.summed_variance + (diff_old * (x - self.mean)).sum(0)
+        self.std = torch.sqrt(torch.clamp(self.summed_variance, min=0.0) / self.count).clamp(1e-6, 1e6)
+
+    def normalize(self, x):
+        return (x - self.mean) / self.std
+
+
+def make_mlp(sizes: Sequence[int], device=None):
+    """flax MLP with swish between layers, lecun_uniform kernels, zero biases (brax networks.MLP)."""
+    import torch
+    layers = []
+    for i in range(len(sizes) - 1):
+        lin = torch.nn.Linear(sizes[i], sizes[i + 1])
+        bound = float(np.sqrt(3.0 / sizes[i]))
+        torch.nn.init.uniform_(lin.weight, -bound, bound)
+        torch.nn.init.zeros_(lin.bias)
+        layers.append(lin)
+        if i < len(sizes) - 2:
+            layers.append(torch.nn.SiLU())
+    return torch.nn.Sequential(*layers).to(device)
+
+
+class PPONetworks:
+    def __init__(self, observation_size: int, action_size: int, device=None, policy_hidden_layer_sizes=(32,) * 4,
+                 value_hidden_layer_sizes=(256,) * 5):
+        self.policy = make_mlp([observation_size, *policy_hidden_layer_sizes, 2 * action_size], device)
+        self.value = make_mlp([observation_size, *value_hidden_layer_sizes, 1], device)
+        self.action_size = action_size
+
+    def parameters(self):
+        return list(self.policy.parameters()) + list(self.value.parameters())
+
+
+def make_inference_fn(networks: PPONetworks, normalizer: Optional[RunningStatistics]):
+    """ppo_networks.make_inference_fn: make_policy(params_unused, deterministic) -> policy(obs, key) -> (action, extras)."""
+    import torch
+
+    def make_policy(_params=None, deterministic: bool = False):
+        def policy(obs, key):
+            with torch.no_grad():
+                x = normalizer.normalize(obs) if normalizer is not None else obs
+                logits = networks.policy(x)
+                if deterministic:
+                    return ppo_losses.tanh_normal_mode(logits), {}
+                loc, scale = ppo_losses._split(logits)
+                gen = torch.Generator(device=obs.device)
+                gen.manual_seed(int(np.asarray(key, dtype=np.uint32)[0]) << 32 | int(np.asarray(key, dtype=np.uint32)[1]))
+                raw = loc + scale * torch.randn(loc.shape, generator=gen, device=obs.device, dtype=loc.dtype)
+                return torch.tanh(raw), {"log_prob": ppo_losses.tanh_normal_log_prob(logits, raw), "raw_action": raw}
+        return policy
+    return make_policy
+
+
+def train(environment, num_timesteps: int, episode_length: int, past_data: Any = None, action_repeat: int = 1, num_envs: int = 1,
+          num_eval_envs: int = 128, learning_rate: float = 1e-4, entropy_cost: float = 1e-4, discounting: float = 0.9, seed: int = 0,
+          unroll_length: int = 10, batch_size: int = 32, num_minibatches: int = 16, num_updates_per_batch: int = 2, num_evals: int = 1,
+          normalize_observations: bool = False, reward_scaling: float = 1.0, clipping_epsilon: float = 0.3, gae_lambda: float = 0.95,
+          rsr_loss_scale: float = 1.0, deterministic_eval: bool = False, progress_fn: Callable[[int, Dict[str, Any]], None] = lambda *a: None,
+          normalize_advantage: bool = True, randomization_fn: Optional[Callable[[Any, np.ndarray], Dict[str, Any]]] = None, wrap_fn: Optional[Callable] = None,
+          policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5):
+    """Returns (make_policy, (normalizer, networks), metrics) as the reference returns (make_policy, params, metrics).
+    `environment` is an env definition with `batched` (AirbotPlayBase, go2.Joystick) or, with `wrap_fn`, anything
+    `wrap_fn(environment, num_envs, episode_length, randomization_fn)` turns into a batched env."""
+    import torch
+    assert batch_size * num_minibatches % num_envs == 0                                   # train.py:160
+    if wrap_fn is None:
+        from ..envs.airbot import wrap as wrap_fn_
+        wrap_fn = lambda e, n, ep, rf: wrap_fn_(e, n, episode_length=ep, action_repeat=action_repeat, randomization_fn=rf)
+    xt = time.time()
+    env_step_per_training_step = batch_size * unroll_length * num_minibatches * action_repeat
+    num_evals_after_init = max(num_evals - 1, 1)
+    num_training_steps_per_epoch = int(np.ceil(num_timesteps / (num_evals_after_init * env_step_per_training_step)))   # train.py:176-183
+    key = prng.PRNGKey(seed)
+    global_key, local_key = prng.split(key, 2)
+    local_key, key_env, eval_key = prng.split(local_key, 3)
+    key_policy, key_value = prng.split(global_key, 2)
+    torch.manual_seed(int(key_policy[0]) << 32 | int(key_policy[1]))
+    # train.py:205-217 / :428-438: randomization_fn(sys, rng) gets one key per env, a different key set for the eval envs
+    key_env, key_rand = prng.split(key_env, 2)
+    rand_for = lambda k, n: (None if randomization_fn is None else (lambda sys: randomization_fn(sys, prng.split(k, n))))
+    env = wrap_fn(environment, num_envs, episode_length, rand_for(key_rand, num_envs))
+    state = env.reset(prng.split(key_env, num_envs))
+    device = state.obs.device
+    obs_size, act_size = state.obs.shape[-1], env.action_size
+    networks = PPONetworks(obs_size, act_size, device, policy_hidden_layer_sizes, value_hidden_layer_sizes)
+    normalizer = RunningStatistics(obs_size, device) if normalize_observations else None
+    optimizer = torch.optim.Adam(networks.parameters(), lr=learning_rate, eps=1e-8)      # optax.adam defaults
+    make_policy = make_inference_fn(networks, normalizer)
+    norm = (lambda o: normalizer.normalize(o)) if normalizer is not None else (lambda o: o)
+    policy_fn = lambda o: networks.policy(norm(o))
+    value_fn = lambda o: networks.value(norm(o)).squeeze(-1)
+    eval_env = wrap_fn(environment, num_eval_envs, episode_length, rand_for(eval_key, num_eval_envs))
+    evaluator = Evaluator(eval_env, lambda p: make_policy(p, deterministic=deterministic_eval), num_eval_envs, episode_length, action_repeat, eval_key)
+    metrics: Dict[str, Any] = {}
+    if num_evals > 1:
+        metrics = evaluator.run_evaluation(None, training_metrics={})
+        progress_fn(0, metrics)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    current_step, training_walltime = 0, 0.0
+    nunroll = batch_size * num_minibatches // num_envs
+    for it in range(num_evals_after_init):
+        t0 = time.time()
+        agg: Dict[str, float] = {}
+        for _ in range(num_training_steps_per_epoch):
+            local_key, key_gen = prng.split(local_key, 2)
+            chunks = []
+            for _u in range(nunroll):                                                     # train.py:310-324
+                key_gen, cur = prng.split(key_gen, 2)
+                state, data = generate_unroll(env, state, make_policy(), cur, unroll_length, extra_fields=("truncation",))
+                chunks.append(data)
+            cat = lambda f: torch.cat([f(c).transpose(0, 1) for c in chunks], dim=0)      # -> [batch_size * num_minibatches, unroll_length, ...]
+            data = Transition(cat(lambda c: c.observation), cat(lambda c: c.action), cat(lambda c: c.reward), cat(lambda c: c.discount),
+                              cat(lambda c: c.next_observation),
+                              {"state_extras": {"truncation": cat(lambda c: c.extras["state_extras"]["truncation"])},
+                               "policy_extras": {k: cat(lambda c, k=k: c.extras["policy_extras"][k]) for k in ("log_prob", "raw_action")}})
+            if normalizer is not None:
+                normalizer.update(data.observation)
+            nb = data.observation.shape[0]
+            for _e in range(num_updates_per_batch):
+                perm = torch.randperm(nb, generator=gen, device=device)
+                for mb in perm.view(num_minibatches, -1):
+                    sub = Transition(data.observation[mb], data.action[mb], data.reward[mb], data.discount[mb], data.next_observation[mb],
+                                     {"state_extras": {"truncation": data.extras["state_extras"]["truncation"][mb]},
+                                      "policy_extras": {k: v[mb] for k, v in data.extras["policy_extras"].items()}})
+                    noise = torch.randn((unroll_length, mb.numel(), act_size), generator=gen, device=device)
+                    loss, m = ppo_losses.compute_ppo_loss(policy_fn, value_fn, sub, noise, past_data=past_data, entropy_cost=entropy_cost,
+                                                          discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
+                                                          clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage,
+                                                          rsr_loss_scale=rsr_loss_scale)
+                    optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
+                    optimizer.step()
+                    for k, v in m.items():
+                        agg[k] = agg.get(k, 0.0) + float(v.detach())
+            current_step += env_step_per_training_step
+        nsteps = num_training_steps_per_epoch * num_updates_per_batch * num_minibatches
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        epoch_time = time.time() - t0
+        training_walltime += epoch_time
+        training_metrics = {"training/sps": num_training_steps_per_epoch * env_step_per_training_step / epoch_time,
+                            "training/walltime": training_walltime, **{f"training/{k}": v / nsteps for k, v in agg.items()}}
+        metrics = evaluator.run_evaluation(None, training_metrics)
+        progress_fn(current_step, metrics)
+    assert current_step >= num_timesteps
+    metrics["walltime"] = time.time() - xt
+    return make_policy, (normalizer, networks), metrics
