@@ -83,7 +83,9 @@ def compute_ppo_loss(policy: Callable, value: Callable, data, entropy_noise, pas
     vs, adv = compute_gae(truncation, termination, rewards, baseline, bootstrap, gae_lambda, discounting)
     if normalize_advantage:
         adv = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)
-    rho = torch.exp(target_lp - behaviour_lp)
+    # exp overflows to inf for a log-ratio above ~88.7 (a collapsed policy scale), and inf * negative advantage turns the whole
+    # update into NaN; capping the exponent at 80 changes the value only where the reference's is inf
+    rho = torch.exp((target_lp - behaviour_lp).clamp(max=80.0))
     policy_loss = -torch.minimum(rho * adv, rho.clamp(1.0 - clipping_epsilon, 1.0 + clipping_epsilon) * adv).mean()
     v_err = vs - baseline
     v_loss = (v_err * v_err).mean() * 0.5 * 0.5

@@ -172,7 +172,11 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
                                                           rsr_loss_scale=rsr_loss_scale)
                     optimizer.zero_grad(set_to_none=True)
                     loss.backward()
-                    optimizer.step()
+                    gn = torch.nn.utils.clip_grad_norm_(networks.parameters(), float("inf"))    # only to read the norm
+                    if torch.isfinite(gn):                                                       # a non-finite gradient would poison Adam's moments for good
+                        optimizer.step()
+                    else:
+                        agg["skipped_updates"] = agg.get("skipped_updates", 0.0) + 1.0
                     for k, v in m.items():
                         agg[k] = agg.get(k, 0.0) + float(v.detach())
             current_step += env_step_per_training_step
