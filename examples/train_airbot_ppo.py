@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=3_000_000)
     ap.add_argument("--evals", type=int, default=6)
     ap.add_argument("--no-dr", action="store_true")
+    ap.add_argument("--entropy-cost", type=float, default=2e-2)
+    ap.add_argument("--learning-rate", type=float, default=1e-4)
     args = ap.parse_args()
     t0 = time.time()
 
@@ -31,7 +33,7 @@ def main():
 
     train(AirbotPlayBase(), num_timesteps=args.timesteps, num_evals=args.evals, reward_scaling=0.1, episode_length=1200,
           normalize_observations=True, action_repeat=1, unroll_length=10, num_minibatches=32, num_updates_per_batch=8,
-          discounting=0.96, learning_rate=1e-4, entropy_cost=2e-2, num_envs=1024, batch_size=256, rsr_loss_scale=0.0,
+          discounting=0.96, learning_rate=args.learning_rate, entropy_cost=args.entropy_cost, num_envs=1024, batch_size=256, rsr_loss_scale=0.0,
           randomization_fn=None if args.no_dr else domain_randomize, seed=0, progress_fn=progress)
     print(f"total {time.time() - t0:.1f} s")
 

@@ -36,7 +36,10 @@ class RunningStatistics:
     def update(self, batch) -> None:
         import torch
         x = batch.reshape(-1, batch.shape[-1]).to(torch.float32)
+        x = x[torch.isfinite(x).all(dim=-1)]            # one non-finite row would poison the statistics for good
         n = x.shape[0]
+        if n == 0:
+            return
         self.count = self.count + n
         diff_old = x - self.mean
         self.mean = self.mean + diff_old.sum(0) / self.count
@@ -156,8 +159,18 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
                               cat(lambda c: c.next_observation),
                               {"state_extras": {"truncation": cat(lambda c: c.extras["state_extras"]["truncation"])},
                                "policy_extras": {k: cat(lambda c, k=k: c.extras["policy_extras"][k]) for k in ("log_prob", "raw_action")}})
+            # A simulation that blows up (seen about once per 1e7 env-steps under a trained policy) yields non-finite
+            # observations until its episode is truncated; such transitions are zeroed and counted instead of being learned from.
+            bad = ~(torch.isfinite(data.observation).all(-1) & torch.isfinite(data.next_observation).all(-1) & torch.isfinite(data.reward)
+                    & torch.isfinite(data.extras["policy_extras"]["raw_action"]).all(-1))
+            if bool(bad.any()):
+                agg["nonfinite_transitions"] = agg.get("nonfinite_transitions", 0.0) + float(bad.sum())
+                data = Transition(torch.nan_to_num(data.observation, 0.0, 0.0, 0.0), data.action, torch.nan_to_num(data.reward, 0.0, 0.0, 0.0),
+                                  data.discount, torch.nan_to_num(data.next_observation, 0.0, 0.0, 0.0),
+                                  {"state_extras": data.extras["state_extras"],
+                                   "policy_extras": {k: torch.nan_to_num(v, 0.0, 0.0, 0.0) for k, v in data.extras["policy_extras"].items()}})
             if normalizer is not None:
-                normalizer.update(data.observation)
+                normalizer.update(data.observation[~bad] if bool(bad.any()) else data.observation)
             nb = data.observation.shape[0]
             for _e in range(num_updates_per_batch):
                 perm = torch.randperm(nb, generator=gen, device=device)
@@ -186,7 +199,8 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
         epoch_time = time.time() - t0
         training_walltime += epoch_time
         training_metrics = {"training/sps": num_training_steps_per_epoch * env_step_per_training_step / epoch_time,
-                            "training/walltime": training_walltime, **{f"training/{k}": v / nsteps for k, v in agg.items()}}
+                            "training/walltime": training_walltime,
+                            **{f"training/{k}": (v if k in ("nonfinite_transitions", "skipped_updates") else v / nsteps) for k, v in agg.items()}}
         metrics = evaluator.run_evaluation(None, training_metrics)
         progress_fn(current_step, metrics)
     assert current_step >= num_timesteps
