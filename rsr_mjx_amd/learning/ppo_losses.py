@@ -75,8 +75,11 @@ def compute_ppo_loss(policy: Callable, value: Callable, data, entropy_noise, pas
     raw_action = sw(data.extras["policy_extras"]["raw_action"])
     behaviour_lp = sw(data.extras["policy_extras"]["log_prob"])
     logits = policy(obs)
-    baseline = value(obs)
-    bootstrap = value(nobs[-1])
+    # asymmetric actor-critic (Playground network_factory value_obs_key="privileged_state"): the critic reads its own stream
+    vobs = sw(data.extras["extra_obs"]["value"]) if "extra_obs" in data.extras and "value" in data.extras["extra_obs"] else obs
+    vnobs = sw(data.extras["next_extra_obs"]["value"]) if "next_extra_obs" in data.extras and "value" in data.extras["next_extra_obs"] else nobs
+    baseline = value(vobs)
+    bootstrap = value(vnobs[-1])
     rewards = reward * reward_scaling
     termination = (1.0 - discount) * (1.0 - truncation)
     target_lp = tanh_normal_log_prob(logits, raw_action)

@@ -102,7 +102,8 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
           normalize_observations: bool = False, reward_scaling: float = 1.0, clipping_epsilon: float = 0.3, gae_lambda: float = 0.95,
           rsr_loss_scale: float = 1.0, deterministic_eval: bool = False, progress_fn: Callable[[int, Dict[str, Any]], None] = lambda *a: None,
           normalize_advantage: bool = True, randomization_fn: Optional[Callable[[Any, np.ndarray], Dict[str, Any]]] = None, wrap_fn: Optional[Callable] = None,
-          policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5):
+          policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5, value_obs_key: Optional[str] = None,
+          max_grad_norm: Optional[float] = None):
     """Returns (make_policy, (normalizer, networks), metrics) as the reference returns (make_policy, params, metrics).
     `environment` is an env definition with `batched` (AirbotPlayBase, go2.Joystick) or, with `wrap_fn`, anything
     `wrap_fn(environment, num_envs, episode_length, randomization_fn)` turns into a batched env."""
@@ -127,13 +128,20 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
     state = env.reset(prng.split(key_env, num_envs))
     device = state.obs.device
     obs_size, act_size = state.obs.shape[-1], env.action_size
+    # value_obs_key: the critic reads another entry of the env's observation dict (locomotion_params.py: "privileged_state")
+    extra_obs = {"value": (lambda st: st.obs_dict[value_obs_key])} if value_obs_key else None
+    vobs_size = state.obs_dict[value_obs_key].shape[-1] if value_obs_key else obs_size
     networks = PPONetworks(obs_size, act_size, device, policy_hidden_layer_sizes, value_hidden_layer_sizes)
+    if value_obs_key:
+        networks.value = make_mlp([vobs_size, *value_hidden_layer_sizes, 1], device)
     normalizer = RunningStatistics(obs_size, device) if normalize_observations else None
+    vnormalizer = RunningStatistics(vobs_size, device) if (normalize_observations and value_obs_key) else None
     optimizer = torch.optim.Adam(networks.parameters(), lr=learning_rate, eps=1e-8)      # optax.adam defaults
     make_policy = make_inference_fn(networks, normalizer)
     norm = (lambda o: normalizer.normalize(o)) if normalizer is not None else (lambda o: o)
     policy_fn = lambda o: networks.policy(norm(o))
-    value_fn = lambda o: networks.value(norm(o)).squeeze(-1)
+    vnorm = (lambda o: vnormalizer.normalize(o)) if vnormalizer is not None else norm
+    value_fn = lambda o: networks.value(vnorm(o)).squeeze(-1)
     eval_env = wrap_fn(environment, num_eval_envs, episode_length, rand_for(eval_key, num_eval_envs))
     evaluator = Evaluator(eval_env, lambda p: make_policy(p, deterministic=deterministic_eval), num_eval_envs, episode_length, action_repeat, eval_key)
     metrics: Dict[str, Any] = {}
@@ -152,13 +160,16 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
             chunks = []
             for _u in range(nunroll):                                                     # train.py:310-324
                 key_gen, cur = prng.split(key_gen, 2)
-                state, data = generate_unroll(env, state, make_policy(), cur, unroll_length, extra_fields=("truncation",))
+                state, data = generate_unroll(env, state, make_policy(), cur, unroll_length, extra_fields=("truncation",), extra_obs=extra_obs)
                 chunks.append(data)
             cat = lambda f: torch.cat([f(c).transpose(0, 1) for c in chunks], dim=0)      # -> [batch_size * num_minibatches, unroll_length, ...]
             data = Transition(cat(lambda c: c.observation), cat(lambda c: c.action), cat(lambda c: c.reward), cat(lambda c: c.discount),
                               cat(lambda c: c.next_observation),
                               {"state_extras": {"truncation": cat(lambda c: c.extras["state_extras"]["truncation"])},
-                               "policy_extras": {k: cat(lambda c, k=k: c.extras["policy_extras"][k]) for k in ("log_prob", "raw_action")}})
+                               "policy_extras": {k: cat(lambda c, k=k: c.extras["policy_extras"][k]) for k in ("log_prob", "raw_action")},
+                               **({"extra_obs": {"value": torch.nan_to_num(cat(lambda c: c.extras["extra_obs"]["value"]), 0.0, 0.0, 0.0)},
+                                   "next_extra_obs": {"value": torch.nan_to_num(cat(lambda c: c.extras["next_extra_obs"]["value"]), 0.0, 0.0, 0.0)}}
+                                  if extra_obs else {})})
             # A simulation that blows up (seen about once per 1e7 env-steps under a trained policy) yields non-finite
             # observations until its episode is truncated; such transitions are zeroed and counted instead of being learned from.
             bad = ~(torch.isfinite(data.observation).all(-1) & torch.isfinite(data.next_observation).all(-1) & torch.isfinite(data.reward)
@@ -167,17 +178,18 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
                 agg["nonfinite_transitions"] = agg.get("nonfinite_transitions", 0.0) + float(bad.sum())
                 data = Transition(torch.nan_to_num(data.observation, 0.0, 0.0, 0.0), data.action, torch.nan_to_num(data.reward, 0.0, 0.0, 0.0),
                                   data.discount, torch.nan_to_num(data.next_observation, 0.0, 0.0, 0.0),
-                                  {"state_extras": data.extras["state_extras"],
+                                  {**data.extras,
                                    "policy_extras": {k: torch.nan_to_num(v, 0.0, 0.0, 0.0) for k, v in data.extras["policy_extras"].items()}})
             if normalizer is not None:
                 normalizer.update(data.observation[~bad] if bool(bad.any()) else data.observation)
+            if vnormalizer is not None:
+                vnormalizer.update(data.extras["extra_obs"]["value"])
             nb = data.observation.shape[0]
             for _e in range(num_updates_per_batch):
                 perm = torch.randperm(nb, generator=gen, device=device)
                 for mb in perm.view(num_minibatches, -1):
                     sub = Transition(data.observation[mb], data.action[mb], data.reward[mb], data.discount[mb], data.next_observation[mb],
-                                     {"state_extras": {"truncation": data.extras["state_extras"]["truncation"][mb]},
-                                      "policy_extras": {k: v[mb] for k, v in data.extras["policy_extras"].items()}})
+                                     {grp: {k: v[mb] for k, v in d.items()} for grp, d in data.extras.items()})
                     noise = torch.randn((unroll_length, mb.numel(), act_size), generator=gen, device=device)
                     loss, m = ppo_losses.compute_ppo_loss(policy_fn, value_fn, sub, noise, past_data=past_data, entropy_cost=entropy_cost,
                                                           discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
@@ -185,7 +197,7 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
                                                           rsr_loss_scale=rsr_loss_scale)
                     optimizer.zero_grad(set_to_none=True)
                     loss.backward()
-                    gn = torch.nn.utils.clip_grad_norm_(networks.parameters(), float("inf"))    # only to read the norm
+                    gn = torch.nn.utils.clip_grad_norm_(networks.parameters(), max_grad_norm if max_grad_norm else float("inf"))
                     if torch.isfinite(gn):                                                       # a non-finite gradient would poison Adam's moments for good
                         optimizer.step()
                     else:

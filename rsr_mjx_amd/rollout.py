@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import time
 from dataclasses import dataclass, field
-from typing import Any, Callable, Dict, Sequence, Tuple
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -53,14 +53,17 @@ def actor_step(env, env_state, policy: Policy, key: np.ndarray, extra_fields: Se
 
 
 def generate_unroll(env, env_state, policy: Policy, key: np.ndarray, unroll_length: int,
-                    extra_fields: Sequence[str] = ()):
+                    extra_fields: Sequence[str] = (), extra_obs: Optional[Dict[str, Callable[[Any], Any]]] = None):
     """`unroll_length` actor steps; returns (final_state, Transition with leaves [T, N, ...]).
 
     Matches brax acting.generate_unroll: step t uses `current_key` of the chain
     `current_key, next_key = split(current_key)`, the transition stores obs_t, action_t, reward_{t+1},
     discount = 1 - done_{t+1}, obs_{t+1} (after auto-reset, as the wrapped env returns it) and
-    extras.state_extras[x] = info[x] after the step."""
+    extras.state_extras[x] = info[x] after the step.  `extra_obs` records further observation streams (e.g. the Go2
+    `privileged_state` an asymmetric critic reads): extras["extra_obs"][name] before and extras["next_extra_obs"][name]
+    after every step."""
     import torch
+    extra_obs = extra_obs or {}
     if unroll_length < 1:
         raise ValueError("unroll_length must be >= 1")
     state = env_state
@@ -76,12 +79,16 @@ def generate_unroll(env, env_state, policy: Policy, key: np.ndarray, unroll_leng
         ks = prng.split(cur, 2)
         step_key, cur = ks[0], ks[1]
         put("observation", t, _obs(state))
+        for name, fn in extra_obs.items():
+            put("xobs/" + name, t, fn(state))
         actions, policy_extras = policy(bufs["observation"][t], step_key)
         state = env.step(state, actions)
         put("action", t, actions)
         put("reward", t, state.reward)
         put("done", t, state.done)
         put("next_observation", t, _obs(state))
+        for name, fn in extra_obs.items():
+            put("nxobs/" + name, t, fn(state))
         for x in extra_fields:
             put("state/" + x, t, state.info[x])
         for k, v in policy_extras.items():
@@ -90,7 +97,9 @@ def generate_unroll(env, env_state, policy: Policy, key: np.ndarray, unroll_leng
         observation=bufs["observation"], action=bufs["action"], reward=bufs["reward"], discount=1.0 - bufs["done"],
         next_observation=bufs["next_observation"],
         extras={"policy_extras": {k[7:]: v for k, v in bufs.items() if k.startswith("policy/")},
-                "state_extras": {k[6:]: v for k, v in bufs.items() if k.startswith("state/")}})
+                "state_extras": {k[6:]: v for k, v in bufs.items() if k.startswith("state/")},
+                **({"extra_obs": {k[5:]: v for k, v in bufs.items() if k.startswith("xobs/")},
+                    "next_extra_obs": {k[6:]: v for k, v in bufs.items() if k.startswith("nxobs/")}} if extra_obs else {})})
     return state, data
 
 
