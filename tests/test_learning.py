@@ -310,3 +310,34 @@ def test_ppo_training_loop_learns_a_multi_step_task():
           policy_hidden_layer_sizes=(32, 32), value_hidden_layer_sizes=(64, 64))
     # untrained mode action ~ 0: about -1.4 per 10-step episode; driving x to zero: about -0.25
     assert hist[0] < -1.0 and hist[-1] > -0.6, hist
+
+
+def test_sac_training_loop_learns_the_point_task():
+    from rsr_mjx_amd.learning.sac_train import ReplayBuffer, train
+    rb = ReplayBuffer(10, 2, 1, None)
+    for k in range(3):
+        rb.insert(torch.full((4, 2), float(k)), torch.zeros(4, 1), torch.full((4,), float(k)), torch.ones(4), torch.zeros(4, 2), torch.zeros(4))
+    assert rb.size == 10 and rb.pos == 2 and set(rb.reward.tolist()) == {0.0, 1.0, 2.0} and (rb.reward[:2] == 2).all()   # ring overwrite
+    s = rb.sample(64, torch.Generator().manual_seed(0))
+    assert s.observation.shape == (64, 2) and s.extras["state_extras"]["truncation"].shape == (64,)
+    hist = []
+    train(None, num_timesteps=6_000, episode_length=10, num_envs=16, num_eval_envs=128, learning_rate=3e-3, discounting=0.9, batch_size=128,
+          num_evals=4, normalize_observations=True, min_replay_size=256, max_replay_size=10_000, grad_updates_per_step=4, deterministic_eval=True,
+          rsr_loss_scale=0.0, progress_fn=lambda s, m: hist.append(float(m["eval/episode_reward"])), wrap_fn=lambda e, n, ep, rf: _PointEnv(n, 10),
+          hidden_layer_sizes=(64, 64))
+    assert len(hist) == 4 and hist[-1] > hist[0] + 0.4 and hist[-1] > -0.8, hist
+    with pytest.raises(ValueError):
+        train(None, 10, 10, rsr_loss_scale=-1.0)
+
+
+@pytest.mark.gpu
+def test_sac_training_runs_on_the_stepper():
+    from rsr_mjx_amd.envs.airbot import AirbotPlaySF, domain_randomize
+    from rsr_mjx_amd.learning.sac_train import train
+    ref = torch.randn(128, 23 + 5 + 23, generator=torch.Generator().manual_seed(0)).cuda()
+    rd = R.build_rsr_data(ref, ref * 1.1 + 0.1, ref * 0.95, num_samples=10, bandwidth=3.0)
+    seen = []
+    _, _, m = train(AirbotPlaySF(), num_timesteps=256 * 60, episode_length=200, past_data=rd, num_envs=256, num_eval_envs=128, learning_rate=3e-4,
+                    batch_size=256, num_evals=3, normalize_observations=True, min_replay_size=1024, max_replay_size=100_000, grad_updates_per_step=2,
+                    rsr_loss_scale=1.0, randomization_fn=domain_randomize, progress_fn=lambda s, mm: seen.append(s))
+    assert len(seen) == 3 and np.isfinite(m["eval/episode_reward"]) and np.isfinite(m["training/critic_loss"]) and m["buffer_current_size"] > 1024
