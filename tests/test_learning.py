@@ -341,3 +341,32 @@ def test_sac_training_runs_on_the_stepper():
                     batch_size=256, num_evals=3, normalize_observations=True, min_replay_size=1024, max_replay_size=100_000, grad_updates_per_step=2,
                     rsr_loss_scale=1.0, randomization_fn=domain_randomize, progress_fn=lambda s, mm: seen.append(s))
     assert len(seen) == 3 and np.isfinite(m["eval/episode_reward"]) and np.isfinite(m["training/critic_loss"]) and m["buffer_current_size"] > 1024
+
+
+def test_pipeline_builds_rsr_data_and_dispatches():
+    from rsr_mjx_amd.learning import pipeline
+    rng = np.random.default_rng(8)
+    s, a = rng.normal(size=(30, 1)), rng.uniform(-1, 1, size=(30, 1))
+    nr, ns, cs = s + 0.2 * a + 0.05, s + 0.2 * a, s + 0.2 * a + 0.01
+    d = pipeline.build_policy_rsr_data(s, a, nr, ns, cs, num_samples=12, bandwidth=1.0, device="cpu")
+    assert d.reference_data.shape == (30, 3) and d.grid.shape == (12, 3) and d.divergence.item() > 0
+    want = O.kl_divergence(O.evaluate_kde(np.hstack([s, a, nr]), d.grid.double().numpy(), 1.0), O.evaluate_kde(np.hstack([s, a, ns]), d.grid.double().numpy(), 1.0))
+    assert d.divergence.item() == pytest.approx(want, rel=2e-3)
+    for bad in ((s[:-1], a, nr, ns, cs), (s, a, nr[:, :0], ns, cs), (s[:0], a[:0], nr[:0], ns[:0], cs[:0]), (s, a.ravel(), nr, ns, cs)):
+        with pytest.raises(ValueError):
+            pipeline.build_policy_rsr_data(*bad, device="cpu")
+    with pytest.raises(ValueError):
+        pipeline.policy_params_training(None, past_states=s, device="cpu")
+    with pytest.raises(ValueError):
+        pipeline.policy_params_training(None, past_states=s, past_actions=a, past_next_states_real=nr, past_next_states_sim=ns,
+                                        current_next_states_sim=cs, algorithm="dqn", device="cpu")
+    seen = []
+    for algo, kw in (("ppo", dict(num_timesteps=2_000, num_envs=16, batch_size=8, num_minibatches=2, num_updates_per_batch=1, unroll_length=5)),
+                     ("SAC ", dict(num_timesteps=400, num_envs=16, batch_size=32, min_replay_size=64))):
+        mk, params = pipeline.policy_params_training(None, progress_fn=lambda st, m: seen.append((algo, st)), past_states=s, past_actions=a,
+                                                     past_next_states_real=nr, past_next_states_sim=ns, current_next_states_sim=cs,
+                                                     algorithm=algo, bandwidth=1.0, rsr_loss_scale=0.5, episode_length=10, num_evals=2,
+                                                     num_eval_envs=16, wrap_fn=lambda e, n, ep, rf: _PointEnv(n, 10), device="cpu", **kw)
+        act, _ = mk(None, deterministic=True)(torch.zeros(4, 1), prng.PRNGKey(0))
+        assert act.shape == (4, 1) and torch.isfinite(act).all()
+    assert {a for a, _ in seen} == {"ppo", "SAC "}
