@@ -40,11 +40,12 @@ class RunningStatistics:
         n = x.shape[0]
         if n == 0:
             return
-        self.count = self.count + n
+        # in place: a captured HIP graph of the update step reads these tensors by address
+        self.count.add_(n)
         diff_old = x - self.mean
-        self.mean = self.mean + diff_old.sum(0) / self.count
-        self.summed_variance = self.summed_variance + (diff_old * (x - self.mean)).sum(0)
-        self.std = torch.sqrt(torch.clamp(self.summed_variance, min=0.0) / self.count).clamp(1e-6, 1e6)
+        self.mean.add_(diff_old.sum(0) / self.count)
+        self.summed_variance.add_((diff_old * (x - self.mean)).sum(0))
+        self.std.copy_(torch.sqrt(torch.clamp(self.summed_variance, min=0.0) / self.count).clamp(1e-6, 1e6))
 
     def normalize(self, x):
         return (x - self.mean) / self.std
@@ -96,6 +97,67 @@ def make_inference_fn(networks: PPONetworks, normalizer: Optional[RunningStatist
     return make_policy
 
 
+class _GraphedUpdate:
+    """One PPO minibatch update (loss, backward, clipping, non-finite guard, Adam step, metric sums) captured once as a HIP
+    graph and replayed: the update is ~500 small kernels (the GAE scan alone is ~10 per time step), so in eager mode its cost is
+    launch latency, not arithmetic.  Inputs are copied into static buffers; everything the captured code reads by address
+    (parameters, Adam moments, normaliser statistics, RSR reference data) is updated in place elsewhere."""
+
+    def __init__(self, loss_fn, optimizer, params, example: Dict[str, Any], max_grad_norm):
+        import torch
+        self.static = {k: torch.zeros_like(v) for k, v in example.items()}
+        self.acc: Dict[str, Any] = {}
+        self._loss_fn, self._opt, self._params, self._gn = loss_fn, optimizer, params, max_grad_norm
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                  # warm-up outside the capture (allocator, lazy Adam state)
+            for k, v in example.items():
+                self.static[k].copy_(v)
+            snapshot = [p.detach().clone() for p in params]
+            for _ in range(3):
+                self._one(accumulate=False)
+            for p, q in zip(params, snapshot):                         # the warm-up must not count as training
+                p.data.copy_(q)
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        self._one(accumulate=False, dry=True)                          # creates the accumulators
+        for v in self.acc.values():
+            v.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self._one(accumulate=True)
+
+    def _one(self, accumulate: bool, dry: bool = False):
+        import torch
+        loss, m = self._loss_fn(self.static)
+        if dry:
+            for k, v in m.items():
+                self.acc[k] = torch.zeros_like(v.detach())
+            self.acc["skipped_updates"] = torch.zeros((), device=loss.device)
+            return
+        self._opt.zero_grad(set_to_none=True)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(self._params, self._gn if self._gn else float("inf"))
+        ok = torch.isfinite(gn)
+        for p_ in self._params:
+            if p_.grad is not None:
+                p_.grad.copy_(torch.where(ok, p_.grad, torch.zeros_like(p_.grad)))
+        self._opt.step()
+        if accumulate:
+            for k, v in m.items():
+                self.acc[k].add_(v.detach())
+            self.acc["skipped_updates"].add_((~ok).to(torch.float32))
+
+    def __call__(self, batch: Dict[str, Any]):
+        for k, v in batch.items():
+            self.static[k].copy_(v)
+        self.graph.replay()
+
+
 def train(environment, num_timesteps: int, episode_length: int, past_data: Any = None, action_repeat: int = 1, num_envs: int = 1,
           num_eval_envs: int = 128, learning_rate: float = 1e-4, entropy_cost: float = 1e-4, discounting: float = 0.9, seed: int = 0,
           unroll_length: int = 10, batch_size: int = 32, num_minibatches: int = 16, num_updates_per_batch: int = 2, num_evals: int = 1,
@@ -103,7 +165,7 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
           rsr_loss_scale: float = 1.0, deterministic_eval: bool = False, progress_fn: Callable[[int, Dict[str, Any]], None] = lambda *a: None,
           normalize_advantage: bool = True, randomization_fn: Optional[Callable[[Any, np.ndarray], Dict[str, Any]]] = None, wrap_fn: Optional[Callable] = None,
           policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5, value_obs_key: Optional[str] = None,
-          max_grad_norm: Optional[float] = None):
+          max_grad_norm: Optional[float] = None, use_graph: Optional[bool] = None):
     """Returns (make_policy, (normalizer, networks), metrics) as the reference returns (make_policy, params, metrics).
     `environment` is an env definition with `batched` (AirbotPlayBase, go2.Joystick) or, with `wrap_fn`, anything
     `wrap_fn(environment, num_envs, episode_length, randomization_fn)` turns into a batched env."""
@@ -136,7 +198,10 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
         networks.value = make_mlp([vobs_size, *value_hidden_layer_sizes, 1], device)
     normalizer = RunningStatistics(obs_size, device) if normalize_observations else None
     vnormalizer = RunningStatistics(vobs_size, device) if (normalize_observations and value_obs_key) else None
-    optimizer = torch.optim.Adam(networks.parameters(), lr=learning_rate, eps=1e-8)      # optax.adam defaults
+    params_list = networks.parameters()
+    if use_graph is None:
+        use_graph = device.type == "cuda"
+    optimizer = torch.optim.Adam(params_list, lr=learning_rate, eps=1e-8, capturable=bool(use_graph))   # optax.adam defaults
     make_policy = make_inference_fn(networks, normalizer)
     norm = (lambda o: normalizer.normalize(o)) if normalizer is not None else (lambda o: o)
     policy_fn = lambda o: networks.policy(norm(o))
@@ -150,11 +215,25 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
         progress_fn(0, metrics)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
+
+    def loss_from_flat(flat):
+        extras: Dict[str, Dict[str, Any]] = {}
+        for k, v in flat.items():
+            if "/" in k:
+                grp, name = k.split("/", 1)
+                extras.setdefault(grp, {})[name] = v
+        sub = Transition(flat["observation"], flat["action"], flat["reward"], flat["discount"], flat["next_observation"], extras)
+        return ppo_losses.compute_ppo_loss(policy_fn, value_fn, sub, flat["noise"], past_data=past_data, entropy_cost=entropy_cost,
+                                           discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
+                                           clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage,
+                                           rsr_loss_scale=rsr_loss_scale)
+    graphed = None
     current_step, training_walltime = 0, 0.0
     nunroll = batch_size * num_minibatches // num_envs
     for it in range(num_evals_after_init):
         t0 = time.time()
         agg: Dict[str, float] = {}
+        dev_agg: Dict[str, Any] = {}
         for _ in range(num_training_steps_per_epoch):
             local_key, key_gen = prng.split(local_key, 2)
             chunks = []
@@ -188,24 +267,42 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
             for _e in range(num_updates_per_batch):
                 perm = torch.randperm(nb, generator=gen, device=device)
                 for mb in perm.view(num_minibatches, -1):
-                    sub = Transition(data.observation[mb], data.action[mb], data.reward[mb], data.discount[mb], data.next_observation[mb],
-                                     {grp: {k: v[mb] for k, v in d.items()} for grp, d in data.extras.items()})
-                    noise = torch.randn((unroll_length, mb.numel(), act_size), generator=gen, device=device)
-                    loss, m = ppo_losses.compute_ppo_loss(policy_fn, value_fn, sub, noise, past_data=past_data, entropy_cost=entropy_cost,
-                                                          discounting=discounting, reward_scaling=reward_scaling, gae_lambda=gae_lambda,
-                                                          clipping_epsilon=clipping_epsilon, normalize_advantage=normalize_advantage,
-                                                          rsr_loss_scale=rsr_loss_scale)
+                    flat = {"observation": data.observation[mb], "action": data.action[mb], "reward": data.reward[mb], "discount": data.discount[mb],
+                            "next_observation": data.next_observation[mb],
+                            **{f"{grp}/{k}": v[mb] for grp, d in data.extras.items() for k, v in d.items()},
+                            "noise": torch.randn((unroll_length, mb.numel(), act_size), generator=gen, device=device)}
+                    if use_graph:
+                        if graphed is None:
+                            try:
+                                graphed = _GraphedUpdate(loss_from_flat, optimizer, params_list, flat, max_grad_norm)
+                            except Exception as exc:                                     # capture not possible: stay eager
+                                print(f"ppo_train: HIP-graph capture failed ({type(exc).__name__}: {exc}); running eager")
+                                use_graph = False
+                        if use_graph:
+                            graphed(flat)
+                            continue
+                    loss, m = loss_from_flat(flat)
                     optimizer.zero_grad(set_to_none=True)
                     loss.backward()
-                    gn = torch.nn.utils.clip_grad_norm_(networks.parameters(), max_grad_norm if max_grad_norm else float("inf"))
-                    if torch.isfinite(gn):                                                       # a non-finite gradient would poison Adam's moments for good
-                        optimizer.step()
-                    else:
-                        agg["skipped_updates"] = agg.get("skipped_updates", 0.0) + 1.0
+                    gn = torch.nn.utils.clip_grad_norm_(params_list, max_grad_norm if max_grad_norm else float("inf"))
+                    # a non-finite gradient would poison Adam's moments for good: such an update gets zero gradients instead.
+                    # Decided on the device (no host round trip per minibatch); metrics are summed on the device as well.
+                    ok = torch.isfinite(gn)
+                    for p_ in params_list:
+                        if p_.grad is not None:
+                            p_.grad = torch.where(ok, p_.grad, torch.zeros_like(p_.grad))
+                    optimizer.step()
+                    dev_agg["skipped_updates"] = dev_agg.get("skipped_updates", 0.0) + (~ok).to(torch.float32)
                     for k, v in m.items():
-                        agg[k] = agg.get(k, 0.0) + float(v.detach())
+                        dev_agg[k] = dev_agg.get(k, 0.0) + v.detach()
             current_step += env_step_per_training_step
         nsteps = num_training_steps_per_epoch * num_updates_per_batch * num_minibatches
+        for k, v in dev_agg.items():
+            agg[k] = agg.get(k, 0.0) + float(v)
+        if graphed is not None:
+            for k, v in graphed.acc.items():
+                agg[k] = agg.get(k, 0.0) + float(v)
+                v.zero_()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         epoch_time = time.time() - t0

@@ -370,3 +370,21 @@ def test_pipeline_builds_rsr_data_and_dispatches():
         act, _ = mk(None, deterministic=True)(torch.zeros(4, 1), prng.PRNGKey(0))
         assert act.shape == (4, 1) and torch.isfinite(act).all()
     assert {a for a, _ in seen} == {"ppo", "SAC "}
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from rsr_mjx_amd.learning.checkpoint import load_params, save_params
+    from rsr_mjx_amd.learning.ppo_train import PPONetworks, RunningStatistics, make_inference_fn
+    torch.manual_seed(0)
+    a, b = PPONetworks(6, 2), PPONetworks(6, 2)
+    na, nb = RunningStatistics(6), RunningStatistics(6)
+    na.update(torch.randn(50, 6) * 3 + 1)
+    obs = torch.randn(5, 6)
+    pa = make_inference_fn(a, na)(None, deterministic=True)(obs, prng.PRNGKey(0))[0]
+    assert not torch.allclose(pa, make_inference_fn(b, nb)(None, deterministic=True)(obs, prng.PRNGKey(0))[0])
+    save_params(str(tmp_path / "ckpt.npz"), (na, a))
+    load_params(str(tmp_path / "ckpt"), (nb, b))
+    assert torch.equal(pa, make_inference_fn(b, nb)(None, deterministic=True)(obs, prng.PRNGKey(0))[0])
+    assert torch.equal(a.value(obs), b.value(obs)) and nb.count.item() == 50
+    with pytest.raises(Exception):
+        load_params(str(tmp_path / "ckpt.npz"), (nb, PPONetworks(7, 2)))
