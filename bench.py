@@ -247,7 +247,7 @@ def main():
                         "(SURVEY.md 8d); the HBM fraction is reported because the metric names it, the VALU fraction beside it",
             },
         }
-        if args.sub_batches > 1 and n % args.sub_batches == 0:
+        if args.sub_batches > 1 and world == 1 and n % args.sub_batches == 0:      # single-GPU extra; multi-GPU runs stay lean
             out["sub_batched"] = sub_batched_rate(envdef, keys, dr, n, ep_len, actions, args.sub_batches, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env.blob, dr, seconds=args.cpu_seconds, nu=nu, act_std=act_std)
