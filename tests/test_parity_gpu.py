@@ -296,3 +296,37 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and "oracle" in c["sample"]
     assert d["value"] > 20 * c["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cube", "go2"])
+def test_odd_batch_sizes_and_argument_errors(setup, kind):
+    """Batch sizes that are not multiples of anything (1, 3, 65): each env is the same env as in a larger batch; wrong
+    action shapes and stepping before reset are refused on the host."""
+    import torch
+    from rsr_mjx_amd import prng
+    if kind == "cube":
+        envdef, nu = setup["envdef"], 5
+        mk = lambda n: envdef.batched(n, episode_length=7, auto_reset=True)
+    else:
+        from rsr_mjx_amd.envs import go2
+        envdef, nu = go2.load("Go2JoystickFlatTerrain"), 12
+        mk = lambda n: envdef.batched(n, episode_length=7, auto_reset=True)
+    keys = prng.split(prng.PRNGKey(21), 65)
+    acts = torch.clamp(torch.randn((12, 65, nu), generator=torch.Generator().manual_seed(1)) * 0.7, -1, 1).cuda()
+    def run(idx):
+        e = mk(len(idx))
+        with pytest.raises(RuntimeError):
+            e.step(None, acts[0, idx])
+        s = e.reset(keys[idx])
+        with pytest.raises(ValueError):
+            e.step(s, acts[0, idx][:, :nu - 1])
+        for t in range(12):
+            s = e.step(s, acts[t, idx])
+        torch.cuda.synchronize()
+        assert torch.isfinite(e.view("obs")).all() and torch.isfinite(e.view("qpos")).all()
+        return e.record.clone().view(torch.int32)      # bit patterns: the Go2 record carries PRNG key words, which are NaNs as floats
+    full = run(list(range(65)))
+    assert torch.equal(run([0]), full[0:1])
+    assert torch.equal(run([3, 4, 5]), full[3:6])
+    assert torch.equal(run([64]), full[64:65])
