@@ -165,7 +165,8 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
           rsr_loss_scale: float = 1.0, deterministic_eval: bool = False, progress_fn: Callable[[int, Dict[str, Any]], None] = lambda *a: None,
           normalize_advantage: bool = True, randomization_fn: Optional[Callable[[Any, np.ndarray], Dict[str, Any]]] = None, wrap_fn: Optional[Callable] = None,
           policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5, value_obs_key: Optional[str] = None,
-          max_grad_norm: Optional[float] = None, use_graph: Optional[bool] = None):
+          max_grad_norm: Optional[float] = None, use_graph: Optional[bool] = None, num_resets_per_eval: int = 0,
+          policy_params_fn: Callable[..., None] = lambda *a: None, restore_checkpoint_path: Optional[str] = None):
     """Returns (make_policy, (normalizer, networks), metrics) as the reference returns (make_policy, params, metrics).
     `environment` is an env definition with `batched` (AirbotPlayBase, go2.Joystick) or, with `wrap_fn`, anything
     `wrap_fn(environment, num_envs, episode_length, randomization_fn)` turns into a batched env."""
@@ -203,6 +204,9 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
         use_graph = device.type == "cuda"
     optimizer = torch.optim.Adam(params_list, lr=learning_rate, eps=1e-8, capturable=bool(use_graph))   # optax.adam defaults
     make_policy = make_inference_fn(networks, normalizer)
+    if restore_checkpoint_path:                                                          # train.py:395-404 (npz instead of orbax)
+        from .checkpoint import load_params
+        load_params(restore_checkpoint_path, (normalizer, networks))
     norm = (lambda o: normalizer.normalize(o)) if normalizer is not None else (lambda o: o)
     policy_fn = lambda o: networks.policy(norm(o))
     vnorm = (lambda o: vnormalizer.normalize(o)) if vnormalizer is not None else norm
@@ -232,6 +236,9 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
     nunroll = batch_size * num_minibatches // num_envs
     for it in range(num_evals_after_init):
         t0 = time.time()
+        if num_resets_per_eval > 0 and it > 0:                                            # train.py:466-480: fresh episodes between evals
+            local_key, key_reset = prng.split(local_key, 2)
+            state = env.reset(prng.split(key_reset, num_envs))
         agg: Dict[str, float] = {}
         dev_agg: Dict[str, Any] = {}
         for _ in range(num_training_steps_per_epoch):
@@ -312,6 +319,7 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
                             **{f"training/{k}": (v if k in ("nonfinite_transitions", "skipped_updates") else v / nsteps) for k, v in agg.items()}}
         metrics = evaluator.run_evaluation(None, training_metrics)
         progress_fn(current_step, metrics)
+        policy_params_fn(current_step, make_policy, (normalizer, networks))              # train.py:493-495 checkpoint hook
     assert current_step >= num_timesteps
     metrics["walltime"] = time.time() - xt
     return make_policy, (normalizer, networks), metrics
