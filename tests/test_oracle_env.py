@@ -317,3 +317,42 @@ def test_tshape_env_follows_T_shape_env_py(tshape_model, oracle_mod):
         np.testing.assert_allclose(st["reward"], np.clip(push + siet + health + site_z, -100, 100), rtol=1e-5)
         assert np.all(st["metrics"][:, 3] == 0)
         np.testing.assert_array_equal(st["done"], (st["xpos"][:, 13, 2] < 0.6).astype(f))
+
+
+def test_oracle_under_address_and_undefined_sanitizers(tmp_path):
+    """SURVEY 5 (race detection / sanitizers): the CPU restatement built with -fsanitize=address,undefined runs reset + steps of
+    every env kind without a report (GPU sanitizers are not available on the pool; the kernels own one env per wave)."""
+    import subprocess, sys, textwrap
+    src = os.path.join(ROOT, "oracle", "rsr_oracle.c")
+    so = tmp_path / "liboracle_f32.so"
+    subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fopenmp", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-DRSR_REAL=float", "-o", str(so), src, "-lm"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    prog = textwrap.dedent(f"""
+        import sys, os
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import numpy as np
+        import oracle.oracle as OM
+        OM._HERE = {str(tmp_path)!r}                      # load the sanitised build instead of oracle/liboracle_f32.so
+        from conftest import make_blob, make_go2_blob
+        from rsr_mjx_amd import prng
+        from rsr_mjx_amd.mjcf import CompiledModel
+        from rsr_mjx_amd.envs import config
+        A = os.path.join({ROOT!r}, "rsr_mjx_amd", "assets")
+        cases = [(make_blob(CompiledModel.load(A + "/airbot_cube.npz"), "cube", episode_length=5, auto_reset=True), 5),
+                 (make_blob(CompiledModel.load(A + "/airbot_tshape.npz"), "tshape", episode_length=5, auto_reset=True), 5),
+                 (make_go2_blob(config.go2_apply_overrides(CompiledModel.load(A + "/go2_rough.npz"), config.GO2_DEFAULT_CONFIG), 5, True), 12)]
+        for blob, nu in cases:
+            orc = OM.Oracle(blob, "f32")
+            st = orc.new_state(6)
+            orc.reset(st, prng.split(prng.PRNGKey(0), 6), 2)
+            rng = np.random.default_rng(0)
+            for t in range(12):
+                orc.step(st, np.clip(rng.normal(size=(6, nu)), -1, 1).astype(np.float32), 2)
+            assert np.isfinite(st["obs"]).all()
+        assert any({str(so)!r} in line for line in open("/proc/self/maps")), "sanitised build was not the one loaded"
+        print("sanitised oracle ok")
+    """)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sanitised oracle ok" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
