@@ -207,6 +207,23 @@ __device__ __forceinline__ void for_bits4(unsigned mask, int nbits, F&& f) {
   }
 }
 
+// Same walk in two phases per trip: `load(i)` of all four bits first (returns a value type), then `use(i, on, value)`.
+// The scheduler keeps the source order of LDS accesses in this kernel, so a load written next to its use -- or after a
+// store that may alias -- waits for its own round trip; gathering the loads in the source is what puts them in flight
+// together.
+template <class L, class U>
+__device__ __forceinline__ void for_bits4_gather(unsigned mask, int nbits, L&& load, U&& use) {
+  for (int t = 0; t < nbits; t += 4) {
+    int i0, i1, i2, i3; bool o0, o1, o2, o3;
+    o0 = mask != 0u; i0 = o0 ? __builtin_ctz(mask) : 0; mask &= mask - 1u;
+    o1 = mask != 0u; i1 = o1 ? __builtin_ctz(mask) : 0; mask &= mask - 1u;
+    o2 = mask != 0u; i2 = o2 ? __builtin_ctz(mask) : 0; mask &= mask - 1u;
+    o3 = mask != 0u; i3 = o3 ? __builtin_ctz(mask) : 0; mask &= mask - 1u;
+    auto v0 = load(i0); auto v1 = load(i1); auto v2 = load(i2); auto v3 = load(i3);
+    use(i0, o0, v0); use(i1, o1, v1); use(i2, o2, v2); use(i3, o3, v3);
+  }
+}
+
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
@@ -396,10 +413,10 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   if (lane < C::NB) {
     unsigned mask = m.body_submask[lane];
     float mm = 0; V3 acc = v3(0, 0, 0);
-    for_bits4(mask, lane == 0 ? C::NB : m.max_sub, [&](int k, bool on) {      // the world's subtree is every body
-      float mk = on ? s.mass[k] : 0.0f;
-      mm += mk; acc = acc + ld3(&s.x.a.xipos[3 * k]) * mk;
-    });
+    struct MP { float m; V3 p; };
+    for_bits4_gather(mask, lane == 0 ? C::NB : m.max_sub,                     // the world's subtree is every body
+      [&](int k) { MP r; r.m = s.mass[k]; r.p = ld3(&s.x.a.xipos[3 * k]); return r; },
+      [&](int, bool on, const MP& r) { float mk = on ? r.m : 0.0f; mm += mk; acc = acc + r.p * mk; });
     V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * lane]) : acc * (1.0f / mm);
     st3(&s.com[3 * lane], c);
   }
@@ -437,7 +454,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
     int b = t / 10, c = t - 10 * b;
     unsigned mask = b == 0 ? 0u : m.body_submask[b];
     float acc = 0;
-    for_bits4(mask, m.max_sub, [&](int k, bool on) { float v = s.x.a.cinert[10 * k + c]; acc += on ? v : 0.0f; });
+    for_bits4_gather(mask, m.max_sub, [&](int k) { return s.x.a.cinert[10 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
     s.x.a.crb[t] = acc;
   }
   WSYNC();
@@ -447,12 +464,20 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
     inert_mul(f, &s.x.a.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
     unsigned mask = m.dof_ancmask[i];
     const float arma = mdl_armature<C>(m, s, i);
-    for_bits4(mask, m.max_chain, [&](int j, bool on) {
-      const float* cj = &s.cdof[6 * j];
-      float v = f[0] * cj[0] + f[1] * cj[1] + f[2] * cj[2] + f[3] * cj[3] + f[4] * cj[4] + f[5] * cj[5];
-      if (j == i) v += arma;
-      if (on) { s.M[i * C::LD + j] = v; s.M[j * C::LD + i] = v; }
-    });
+    // Exhausted masks store into the row's padding word M[i][NV] rather than being predicated off (a predicated store
+    // drags its loads into the exec region, where they wait one by one).
+    const int pad = i * C::LD + C::NV;
+    struct C6 { float c[6]; };
+    for_bits4_gather(mask, m.max_chain,
+      [&](int j) { C6 r;
+#pragma unroll
+                   for (int k = 0; k < 6; ++k) r.c[k] = s.cdof[6 * j + k];
+                   return r; },
+      [&](int j, bool on, const C6& r) {
+        float v = f[0] * r.c[0] + f[1] * r.c[1] + f[2] * r.c[2] + f[3] * r.c[3] + f[4] * r.c[4] + f[5] * r.c[5];
+        if (j == i) v += arma;
+        s.M[on ? i * C::LD + j : pad] = v; s.M[on ? j * C::LD + i : pad] = v;
+      });
   }
   WSYNC();
 }
@@ -746,19 +771,23 @@ __device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
     float h = (side < 2) ? job.hu : job.hv;
     float sg = (side & 1) ? -1.0f : 1.0f;
     float* P = scr + cur * 24; float* Qn = scr + (1 - cur) * 24;
-    const float* cx = (side < 2) ? P : P + 8;
+    // the current vertex is carried in registers and the next one is loaded before anything is stored: stores to the
+    // other polygon may alias as far as the compiler knows, and a load issued after them waits for its own round trip
+    float x1 = P[0], y1 = P[8], z1 = P[16];
     int nn = 0;
     for (int i = 0; i < np; ++i) {
-      int i2 = (i + 1 == np) ? 0 : i + 1;
-      float d1 = h - sg * cx[i], d2 = h - sg * cx[i2];
-      if (d1 >= 0.0f) { Qn[nn] = P[i]; Qn[8 + nn] = P[8 + i]; Qn[16 + nn] = P[16 + i]; nn++; }
+      const int i2 = (i + 1 == np) ? 0 : i + 1;
+      const float x2 = P[i2], y2 = P[8 + i2], z2 = P[16 + i2];
+      float d1 = h - sg * (side < 2 ? x1 : y1), d2 = h - sg * (side < 2 ? x2 : y2);
+      if (d1 >= 0.0f) { Qn[nn] = x1; Qn[8 + nn] = y1; Qn[16 + nn] = z1; nn++; }
       if ((d1 >= 0.0f) != (d2 >= 0.0f)) {
         float tt = d1 / (d1 - d2);
-        Qn[nn] = P[i] + tt * (P[i2] - P[i]);
-        Qn[8 + nn] = P[8 + i] + tt * (P[8 + i2] - P[8 + i]);
-        Qn[16 + nn] = P[16 + i] + tt * (P[16 + i2] - P[16 + i]);
+        Qn[nn] = x1 + tt * (x2 - x1);
+        Qn[8 + nn] = y1 + tt * (y2 - y1);
+        Qn[16 + nn] = z1 + tt * (z2 - z1);
         nn++;
       }
+      x1 = x2; y1 = y2; z1 = z2;
     }
     np = nn; cur = 1 - cur;
     if (np == 0) return;
@@ -926,17 +955,21 @@ __device__ __forceinline__ void motion_cross(float* o, const float* u, const flo
   st3(o + 3, cross(ul, va) + cross(ua, vl));
 }
 
+struct Q6 { float qd; float c[6]; };      // one chain dof: its velocity and a spatial vector
 template <class C>
 __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
   // cvel[b] = sum over the dofs on b's chain of cdof*qvel
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
     float v[6] = {0, 0, 0, 0, 0, 0};
-    for_bits4(mask, m.max_chain, [&](int i, bool on) {
-      float qd = on ? s.qvel[i] : 0.0f;
+    for_bits4_gather(mask, m.max_chain,
+      [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
-    });
+                   for (int c = 0; c < 6; ++c) r.c[c] = s.cdof[6 * i + c];
+                   return r; },
+      [&](int, bool on, const Q6& r) { float qd = on ? r.qd : 0.0f;
+#pragma unroll
+                   for (int c = 0; c < 6; ++c) v[c] += r.c[c] * qd; });
 #pragma unroll
     for (int c = 0; c < 6; ++c) s.x.a.cvel[6 * lane + c] = v[c];
   }
@@ -945,11 +978,14 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     unsigned mask = m.dof_velmask[lane];
     bool free_trans = (m.dof_jtype[lane] == JNT_FREE) && (m.dof_k[lane] < 3);
     float v[6] = {0, 0, 0, 0, 0, 0};
-    for_bits4(mask, m.max_chain, [&](int i, bool on) {
-      float qd = on ? s.qvel[i] : 0.0f;
+    for_bits4_gather(mask, m.max_chain,
+      [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] += s.cdof[6 * i + c] * qd;
-    });
+                   for (int c = 0; c < 6; ++c) r.c[c] = s.cdof[6 * i + c];
+                   return r; },
+      [&](int, bool on, const Q6& r) { float qd = on ? r.qd : 0.0f;
+#pragma unroll
+                   for (int c = 0; c < 6; ++c) v[c] += r.c[c] * qd; });
     float o[6];
     motion_cross(o, v, &s.cdof[6 * lane]);
 #pragma unroll
@@ -967,11 +1003,14 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   if (lane < C::NB) {
     unsigned mask = m.body_dofmask[lane];
     float a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-    for_bits4(mask, m.max_chain, [&](int i, bool on) {
-      float qd = on ? s.qvel[i] : 0.0f;
+    for_bits4_gather(mask, m.max_chain,
+      [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a[c] += s.x.a.cdofdot[6 * i + c] * qd;
-    });
+                   for (int c = 0; c < 6; ++c) r.c[c] = s.x.a.cdofdot[6 * i + c];
+                   return r; },
+      [&](int, bool on, const Q6& r) { float qd = on ? r.qd : 0.0f;
+#pragma unroll
+                   for (int c = 0; c < 6; ++c) a[c] += r.c[c] * qd; });
     if constexpr (C::XFRC) {
       if (lane == s.acc_body) {
 #pragma unroll
@@ -991,7 +1030,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     int b = t / 6, c = t - 6 * b;
     unsigned mask = m.body_submask[b];
     float acc = 0;
-    for_bits4(mask, m.max_sub, [&](int k, bool on) { float v = s.x.a.cfrc[6 * k + c]; acc += on ? v : 0.0f; });
+    for_bits4_gather(mask, m.max_sub, [&](int k) { return s.x.a.cfrc[6 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
     s.x.a.cfrcsum[t] = acc;
   }
   WSYNC();

@@ -275,12 +275,12 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     if (bi != bj) s.T[i0 * C::LD + j0 + 1] = h01;     // diagonal blocks: (i0, i0+1) is upper, never read
   }
   WSYNC();
+  // Row `lane` of T, unmasked: chol_factor never consumes a[j] of a lane < j before zeroing it, and lanes >= NV (which
+  // read row 0) are never read by anyone.  (A select on the loaded value makes the compiler wrap every load in its own
+  // exec-mask region with a wait inside: 20 serialised LDS round trips.)
+  const float* Trow = &s.T[(lane < C::NV ? lane : 0) * C::LD];
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) {
-    // unconditional in-bounds load, then a select: a load under a per-j condition is a separate exec-mask region each
-    const float t = s.T[(lane < C::NV ? lane : 0) * C::LD + j];
-    a[j] = (lane < C::NV && j <= lane) ? t : 0.0f;
-  }
+  for (int j = 0; j < C::NV; ++j) a[j] = Trow[j];
   WSYNC();
   PROF(PS_H_XCHG)
   const float dinv = chol_factor<C>(a, lt, s.T, lane);
@@ -429,7 +429,7 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   PROF(PS_KIN)
   com_crb_mass<C>(m, s, lane);
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) Mrow[j] = lane < C::NV ? s.M[lane * C::LD + j] : 0.0f;
+  for (int j = 0; j < C::NV; ++j) Mrow[j] = s.M[(lane < C::NV ? lane : 0) * C::LD + j];   // lanes >= NV: row 0, every use is masked
   PROF(PS_COMCRB)
   // velocity stage first: its scratch and the frames die before the Jacobian claims the shared LDS region
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
@@ -438,7 +438,7 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   // qacc_smooth = M^-1 qfrc_smooth
   float a[C::NV], lt[C::NV];
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] : 0.0f;
+  for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j];        // entries j > lane are never consumed by chol_factor
   const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
   PROF(PS_CHOLM)
@@ -506,7 +506,7 @@ __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane,
     float a[C::NV], lt[C::NV];
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < C::NV; ++j) a[j] = (j <= lane) ? Mrow[j] + (j == lane ? dd : 0.0f) : 0.0f;
+    for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j] + (j == lane ? dd : 0.0f);
     const float dinv_i = chol_factor<C, true>(a, lt, s.T, lane);
     qacc = lane < C::NV ? chol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane) : 0.0f;
   }
