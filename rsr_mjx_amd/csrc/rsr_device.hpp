@@ -178,11 +178,35 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 __device__ __forceinline__ float rdlane(float v, int l);
 // rows 1,3 += lane 15 of the row below; rows 2,3 += lane 31: lane 63 then holds the wave total
+// Hand-scheduled: the compiler emits every chain on its own with an s_nop between dependent DPP steps (a DPP read
+// needs two wait states after the write) and builds the two row_bcast steps from mov 0 / mov_dpp / add -- 19 issue slots
+// per sum.  Written out, a chain is six DPP adds; three chains interleaved fill each other's wait states.
+#define RSR_DPP_STEP3(ctrl) \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t"
+#define RSR_DPP_STEP1(ctrl) "v_add_f32_dpp %0, %0, %0 " ctrl "\n\ts_nop 1\n\t"
+#define RSR_DPP_FULL " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+// the three wave totals, in place (same pairing of the additions as wave_sum: results are bit-identical)
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t"
+               RSR_DPP_STEP3("quad_perm:[1,0,3,2]" RSR_DPP_FULL)
+               RSR_DPP_STEP3("quad_perm:[2,3,0,1]" RSR_DPP_FULL)
+               RSR_DPP_STEP3("row_half_mirror" RSR_DPP_FULL)
+               RSR_DPP_STEP3("row_mirror" RSR_DPP_FULL)
+               RSR_DPP_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               RSR_DPP_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c));
+  a = rdlane(a, 63); b = rdlane(b, 63); c = rdlane(c, 63);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-  v = row_sum16(v);
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  asm volatile("s_nop 1\n\t"
+               RSR_DPP_STEP1("quad_perm:[1,0,3,2]" RSR_DPP_FULL)
+               RSR_DPP_STEP1("quad_perm:[2,3,0,1]" RSR_DPP_FULL)
+               RSR_DPP_STEP1("row_half_mirror" RSR_DPP_FULL)
+               RSR_DPP_STEP1("row_mirror" RSR_DPP_FULL)
+               RSR_DPP_STEP1("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(v));
+  return rdlane(v, 63);
 }
 __device__ __forceinline__ float rdlane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -231,7 +255,9 @@ enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);          // nothing is scheduled across a stamp (the asm alone only pins memory operations)
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
   return t;
 }
 #define PROF_DECL Prof prof_; for (int i_ = 0; i_ < PS_COUNT; ++i_) prof_.acc[i_] = 0; prof_.t0 = prof_now();

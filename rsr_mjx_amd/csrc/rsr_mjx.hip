@@ -205,7 +205,10 @@ __device__ void go2_accelerometer(const DModel& m, const Smem<C>& s, int lane, f
   const bool on = lane < C::NV && ((m.body_dofmask[b] >> lane) & 1);
   float c6[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) c6[c] = wave_sum(on ? s.cdof[6 * lane + c] * qacc_i : 0.0f) + s.accb[c];
+  for (int c = 0; c < 6; ++c) c6[c] = on ? s.cdof[6 * lane + c] * qacc_i : 0.0f;
+  wave_sum3(c6[0], c6[1], c6[2]); wave_sum3(c6[3], c6[4], c6[5]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) c6[c] += s.accb[c];
   V3 dif = ld3(&s.spos[3 * imu]) - ld3(&s.com[3 * m.body_rootid[b]]);
   V3 ang = v3(c6[0], c6[1], c6[2]), lin = v3(c6[3], c6[4], c6[5]) + cross(ang, dif);
   const float* R = &s.smat[9 * imu];

@@ -51,7 +51,7 @@ template <class C>
 __device__ __forceinline__ int row_kind(int r) { return r < C::NEQ ? 0 : (r < C::NEQ + C::NF ? 1 : 2); }
 
 // cost of the constraint rows at Jaref; optionally emits force and Hessian weight per row
-template <class C>
+template <class C, bool REDUCE = true>
 __device__ __forceinline__ float rows_cost(int lane, int nefc, const float (&jaref)[C::NCHUNK], const RowRegs (&rr)[C::NCHUNK],
                                            float (&force)[C::NCHUNK], float (&hw)[C::NCHUNK]) {
   float cost = 0;
@@ -72,7 +72,7 @@ __device__ __forceinline__ float rows_cost(int lane, int nefc, const float (&jar
     if (act) { f = -D * x; cost += 0.5f * D * x * x; w = D; }
     force[ch] = f; hw[ch] = w;
   }
-  return wave_sum(cost);
+  return REDUCE ? wave_sum(cost) : cost;      // !REDUCE: this lane's share, for a caller that reduces several sums together
 }
 
 struct LSPoint { float alpha, cost, d0, d1; };
@@ -137,10 +137,7 @@ __device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], con
     }
   }
 #pragma unroll
-  for (int p = 0; p < NPT; ++p) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) q[p][c] = wave_sum(q[p][c]);     // independent DPP chains, interleaved by the scheduler
-  }
+  for (int p = 0; p < NPT; ++p) wave_sum3(q[p][0], q[p][1], q[p][2]);
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
     float q0 = q[p][0] + g0, q1 = q[p][1] + g1, q2 = q[p][2] + g2, al = alpha[p];
@@ -304,13 +301,15 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   jdot<C>(s, lane, nefc, nbase, rr, warm, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
-  float cost_w = rows_cost<C>(lane, nefc, jaref, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_w - fs) * (warm - a0) : 0.0f);
+  float cost_w = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw), gs_w = dofl ? (Ma_w - fs) * (warm - a0) : 0.0f, unused = 0.0f;
+  wave_sum3(cost_w, gs_w, unused);
+  cost_w += 0.5f * gs_w;
   float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
   float jar_s[C::NCHUNK];
   jdot<C>(s, lane, nefc, nbase, rr, a0, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
-  float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw) + 0.5f * wave_sum(dofl ? (Ma_s - fs) * (a0 - a0) : 0.0f);
+  float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw);      // (its Gauss term (Ma_s - fs).(a0 - a0) is zero)
   const bool use_warm = cost_w < cost_s;
   float qacc = use_warm ? warm : a0, Ma = use_warm ? Ma_w : Ma_s;
   if (!use_warm) {
@@ -319,8 +318,11 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   }
   // --- context at the start point ---
   float gauss, cost, prev_cost = INFINITY;
-  float rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
-  gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
+  float rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
+  gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
+  unused = 0.0f;
+  wave_sum3(rc, gauss, unused);
+  gauss *= 0.5f;
   cost = rc + gauss;
   float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
@@ -340,12 +342,13 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     } else done = iter >= 1;
     if (uniform_i(done)) break;
     // ---------------- line search ----------------
-    float snorm = sqrtf(wave_sum(search * search));
-    float gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * (float)(C::NV > 1 ? C::NV : 1);
     float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
     jdot<C>(s, lane, nefc, nbase, rr, search, jv);
-    float g1 = wave_sum(search * Ma) - wave_sum(search * fs);
-    float g2 = 0.5f * wave_sum(search * mv);
+    float snorm = search * search, g1a = search * Ma, g1b = search * fs;
+    wave_sum3(snorm, g1a, g1b);
+    snorm = sqrtf(snorm);
+    float gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * (float)(C::NV > 1 ? C::NV : 1);
+    float g1 = g1a - g1b;
     // fp32 noise floor of the 1-D derivative: d0(alpha) = 2 alpha q2 + q1 is a sum of up to NEFC terms, so values
     // below eps * (sum |q1 terms| + 2 |alpha| sum |q2 terms|) are indistinguishable from zero.  MJX's gtol
     // (tolerance * ls_tolerance * |search| * scale ~ 1e-6) is below that floor in fp32 and the reference loop
@@ -356,8 +359,13 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
       n1 += fabsf(jv[ch] * jaref[ch] * rr[ch].D) + (rr[ch].floss > 0.0f ? fabsf(rr[ch].floss * jv[ch]) : 0.0f);
       n2 += 0.5f * jv[ch] * jv[ch] * rr[ch].D;
     }
-    n1 = wave_sum(n1) + wave_sum(fabsf(search * Ma)) + wave_sum(fabsf(search * fs));
-    n2 = wave_sum(n2) + fabsf(g2);
+    float g2 = search * mv, n1a = fabsf(search * Ma), n1b = fabsf(search * fs);
+    wave_sum3(g2, n1a, n1b);
+    g2 *= 0.5f;
+    float zero = 0.0f;
+    wave_sum3(n1, n2, zero);
+    n1 = (n1 + n1a) + n1b;
+    n2 += fabsf(g2);
     // Only for converging solves: with iterations == 1 (Go2) the reference's truncated procedure IS the answer.
     const float NOISE = m.iterations > 1 ? 1.1920929e-7f : 0.0f;
     PROF(PS_LS_SETUP)
@@ -400,8 +408,11 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
       for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] += alpha * jv[ch];
     }
     // ---------------- update constraint + gradient ----------------
-    rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
-    gauss = 0.5f * wave_sum(dofl ? (Ma - fs) * (qacc - a0) : 0.0f);
+    rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
+    gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
+    unused = 0.0f;
+    wave_sum3(rc, gauss, unused);
+    gauss *= 0.5f;
     prev_cost = cost; cost = rc + gauss;
     PROF(PS_X6)
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
