@@ -50,6 +50,8 @@ struct DModel {
   const int *pair_b1, *pair_b2, *pair_root1, *pair_root2, *dof_rootid, *dof_jtype, *dof_k, *dof_act, *dof_afl, *body_jtype, *body_qposadr;
   const unsigned *pair_mask1, *pair_mask2;
   const float *pair_tw, *pair_incl, *dof_afrange, *body_jpos, *body_jaxis;
+  // per-lane constant records [LQ_COUNT][64] of 16-byte quads (rsr_mjx_amd/model.py: lane_records)
+  const int4* lane_rec;
   // height field (at most one): size = (x, y, z, base) half extents / elevation scale, data [nrow*ncol] in [0, 1]
   const float *hfield_size, *hfield_data;
   const int *hfield_nrow, *hfield_ncol;
@@ -331,6 +333,28 @@ template <class C> __device__ __forceinline__ float mdl_armature(const DModel& m
 template <class C> __device__ __forceinline__ float mdl_gain(const DModel& m, const Smem<C>& s, int k) { if constexpr (C::DREX) return s.dx_gain[k]; else return m.actuator_gainprm[k]; }
 template <class C> __device__ __forceinline__ float mdl_bias(const DModel& m, const Smem<C>& s, int k) { if constexpr (C::DREX) return s.dx_bias[k]; else return m.actuator_biasprm[k]; }
 
+// ---- per-lane constant records (model.py lane_records) ----
+// A lane is body l, joint l, geom l, site l and dof l at once.  Reading its constants from the per-field tables is a
+// scalar pointer load followed by a vector load PER FIELD, each pair a few hundred cycles and mostly serialised by the
+// control flow around them; a stage instead fetches the quads it needs at its top: coalesced 16-byte loads, all in
+// flight together, one wait.  Lanes past a role's count read zeros.
+enum LaneQuad { LQ_B_IDS = 0, LQ_B_POS, LQ_B_QUAT, LQ_B_JPOS, LQ_B_JAX, LQ_B_IQUAT, LQ_B_MISC, LQ_B_INERTIA,
+                LQ_J_IDS, LQ_J_BQUAT, LQ_J_BPOS, LQ_J_POSAX, LQ_J_AX, LQ_G_POS, LQ_G_QUAT, LQ_S_POS, LQ_S_QUAT,
+                LQ_D_IDS, LQ_D_MASKS, LQ_D_ACT, LQ_D_CTRL, LQ_D_BIAS, LQ_D_FRC, LQ_COUNT };
+__device__ __forceinline__ int4 lrec(const DModel& m, int quad, int lane) { return m.lane_rec[quad * 64 + lane]; }
+// The lane index a stage passes to lrec: `lane` plus a zero the optimiser cannot see through.  The records are loop
+// invariant, and hoisted out of the substep loop they would stay live across the solver, where every register is taken:
+// they would be spilled there and come back from scratch memory instead.
+__device__ __forceinline__ int lrec_lane(int lane) {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return lane + z;
+}
+__device__ __forceinline__ float asf(int x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ V3 v3_xyz(int4 r) { return V3{asf(r.x), asf(r.y), asf(r.z)}; }
+__device__ __forceinline__ V3 v3_yzw(int4 r) { return V3{asf(r.y), asf(r.z), asf(r.w)}; }
+__device__ __forceinline__ Q4 q4_of(int4 r) { return Q4{asf(r.x), asf(r.y), asf(r.z), asf(r.w)}; }
+
 // =====================================================================================
 // stage 1: kinematics (MJX smooth.kinematics).  Lane b first builds body b's transform relative to its
 // parent, joint included (one sincos for all hinges at once); the tree is then composed level by level,
@@ -339,15 +363,24 @@ template <class C> __device__ __forceinline__ float mdl_bias(const DModel& m, co
 // =====================================================================================
 template <class C>
 __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
-  static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64, "one lane per body / geom / joint");
+  const int lr = lrec_lane(lane);
+  static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64 && C::NS <= 64, "one lane per body / geom / joint / site");
+  // every model constant of the stage, for all of this lane's roles
+  const int4 rb_ids = lrec(m, LQ_B_IDS, lr), rb_pos = lrec(m, LQ_B_POS, lr), rb_quat = lrec(m, LQ_B_QUAT, lr);
+  const int4 rb_jpos = lrec(m, LQ_B_JPOS, lr), rb_jax = lrec(m, LQ_B_JAX, lr), rb_iquat = lrec(m, LQ_B_IQUAT, lr);
+  const int4 rb_misc = lrec(m, LQ_B_MISC, lr);
+  const int4 rj_ids = lrec(m, LQ_J_IDS, lr), rj_bquat = lrec(m, LQ_J_BQUAT, lr), rj_bpos = lrec(m, LQ_J_BPOS, lr);
+  const int4 rj_posax = lrec(m, LQ_J_POSAX, lr), rj_ax = lrec(m, LQ_J_AX, lr);
+  const int4 rg_pos = lrec(m, LQ_G_POS, lr), rg_quat = lrec(m, LQ_G_QUAT, lr);
+  const int4 rs_pos = lrec(m, LQ_S_POS, lr), rs_quat = lrec(m, LQ_S_QUAT, lr);
   const int b = lane < C::NB ? lane : 0;
-  const int parent = m.body_parentid[b], depth = lane < C::NB ? m.body_depth[b] : -1;
-  V3 bp = ld3(&m.body_pos[3 * b]);
-  Q4 bq = ld4(&m.body_quat[4 * b]);
+  const int parent = rb_ids.x, depth = lane < C::NB ? rb_ids.y : -1;
+  V3 bp = v3_xyz(rb_pos);
+  Q4 bq = q4_of(rb_quat);
   V3 lp = bp; Q4 lq = bq;
-  const int jt = lane < C::NB ? m.body_jtype[b] : -1;
+  const int jt = lane < C::NB ? rb_ids.z : -1;
   if (jt >= 0) {
-    const int qa = m.body_qposadr[b];
+    const int qa = rb_ids.w;
     if (jt == JNT_FREE) {
       lp = ld3(&s.qpos[qa]);
       lq = ld4(&s.qpos[qa + 3]);
@@ -356,8 +389,10 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
       else { float inv = 1.0f / n; lq = Q4{lq.w * inv, lq.x * inv, lq.y * inv, lq.z * inv}; }
       st4(&s.qpos[qa + 3], lq);                    // MJX writes the normalised quaternion back
     } else {
-      V3 jp = ld3(&m.body_jpos[3 * b]), jax = ld3(&m.body_jaxis[3 * b]);
-      float dq = s.qpos[qa] - mdl_qpos0<C>(m, s, qa);
+      V3 jp = v3_xyz(rb_jpos), jax = V3{asf(rb_jpos.w), asf(rb_jax.x), asf(rb_jax.y)};
+      float q0;
+      if constexpr (C::DREX) q0 = s.dx_qpos0[qa]; else q0 = asf(rb_pos.w);
+      float dq = s.qpos[qa] - q0;
       if (jt == JNT_HINGE) {
         float sn, cs;
         sincosf(dq * 0.5f, &sn, &cs);
@@ -382,36 +417,38 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
     M33 R = q2m(q);
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.xmat[9 * b + c] = R.m[c];
-    st3(&s.x.a.xipos[3 * b], pos + mulv(R, mdl_ipos<C>(m, s, b)));
-    M33 Ri = q2m(qmul(q, ld4(&m.body_iquat[4 * b])));
+    V3 ipos;
+    if constexpr (C::DREX) ipos = ld3(&s.dx_ipos[3 * b]); else ipos = V3{asf(rb_jax.z), asf(rb_jax.w), asf(rb_misc.x)};
+    st3(&s.x.a.xipos[3 * b], pos + mulv(R, ipos));
+    M33 Ri = q2m(qmul(q, q4_of(rb_iquat)));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.ximat[9 * b + c] = Ri.m[c];
   }
   WSYNC();
   if (lane < C::NJ) {          // joint anchors / axes in the world frame (frame of the body before the joint acts)
-    int j = lane, jb = m.jnt_bodyid[j], jpar = m.body_parentid[jb];
-    if (m.jnt_type[j] == JNT_FREE) {
+    const int j = lane, jb = rj_ids.x, jpar = rj_ids.y;
+    if (rj_ids.z == JNT_FREE) {
       st3(&s.x.a.xanchor[3 * j], ld3(&s.xpos[3 * jb])); st3(&s.x.a.xaxis[3 * j], v3(0, 0, 1));
     } else {
       Q4 pq = ld4(&s.xquat[4 * jpar]);
-      Q4 qpre = qmul(pq, ld4(&m.body_quat[4 * jb]));
-      V3 ppre = ld3(&s.xpos[3 * jpar]) + qrot(pq, ld3(&m.body_pos[3 * jb]));
-      st3(&s.x.a.xanchor[3 * j], ppre + qrot(qpre, ld3(&m.jnt_pos[3 * j])));
-      st3(&s.x.a.xaxis[3 * j], qrot(qpre, ld3(&m.jnt_axis[3 * j])));
+      Q4 qpre = qmul(pq, q4_of(rj_bquat));
+      V3 ppre = ld3(&s.xpos[3 * jpar]) + qrot(pq, v3_xyz(rj_bpos));
+      st3(&s.x.a.xanchor[3 * j], ppre + qrot(qpre, V3{asf(rj_bpos.w), asf(rj_posax.x), asf(rj_posax.y)}));
+      st3(&s.x.a.xaxis[3 * j], qrot(qpre, V3{asf(rj_posax.z), asf(rj_posax.w), asf(rj_ax.x)}));
     }
   }
   if (lane < C::NG) {
-    int g = lane, gb = m.geom_bodyid[g];
+    const int g = lane, gb = rg_pos.x;
     Q4 gq = ld4(&s.xquat[4 * gb]);
-    st3(&s.x.a.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.x.a.xmat[9 * gb], ld3(&m.geom_pos[3 * g])));
-    M33 Rg = q2m(qmul(gq, ld4(&m.geom_quat[4 * g])));
+    st3(&s.x.a.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.x.a.xmat[9 * gb], v3_yzw(rg_pos)));
+    M33 Rg = q2m(qmul(gq, q4_of(rg_quat)));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.x.a.gmat[9 * g + c] = Rg.m[c];
   }
   if (lane < C::NS) {
-    int sb = m.site_bodyid[lane];
-    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.x.a.xmat[9 * sb], ld3(&m.site_pos[3 * lane])));
-    M33 Rs = q2m(qmul(ld4(&s.xquat[4 * sb]), ld4(&m.site_quat[4 * lane])));
+    const int sb = rs_pos.x;
+    st3(&s.spos[3 * lane], ld3(&s.xpos[3 * sb]) + mulv(&s.x.a.xmat[9 * sb], v3_yzw(rs_pos)));
+    M33 Rs = q2m(qmul(ld4(&s.xquat[4 * sb]), q4_of(rs_quat)));
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.smat[9 * lane + c] = Rs.m[c];
   }
@@ -434,13 +471,27 @@ __device__ __forceinline__ void inert_mul(float* o, const float* i, const float*
 // =====================================================================================
 template <class C>
 __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
+  const int lr = lrec_lane(lane);
+  const int4 rb_misc = lrec(m, LQ_B_MISC, lr), rb_inertia = lrec(m, LQ_B_INERTIA, lr);
+  const int4 rd_ids = lrec(m, LQ_D_IDS, lr), rd_masks = lrec(m, LQ_D_MASKS, lr);
+  const int max_sub = m.max_sub, max_chain = m.max_chain;
+  // subtree masks of the bodies whose composite inertia items this lane sums below: body b's mask sits in lane b's record,
+  // and a cross-lane read needs its source lane active, so fetch them here, outside the ragged loop
+  constexpr int NPASS_CRB = (C::NB * 10 + 63) / 64;
+  unsigned crb_mask[NPASS_CRB];
+#pragma unroll
+  for (int p = 0; p < NPASS_CRB; ++p) {
+    const int bb = (lane + 64 * p) / 10;
+    const unsigned mb = (unsigned)__shfl(rb_misc.z, bb < C::NB ? bb : 0);     // unconditional: every source lane must be active
+    crb_mask[p] = (bb == 0 || bb >= C::NB) ? 0u : mb;
+  }
   if (lane < C::NEG) st3(&s.egeom[3 * lane], ld3(&s.x.a.gpos[3 * m.env_ids[C::EG0 + lane]]));
   // subtree centre of mass: lane b sums its subtree
   if (lane < C::NB) {
-    unsigned mask = m.body_submask[lane];
+    unsigned mask = (unsigned)rb_misc.z;
     float mm = 0; V3 acc = v3(0, 0, 0);
     struct MP { float m; V3 p; };
-    for_bits4_gather(mask, lane == 0 ? C::NB : m.max_sub,                     // the world's subtree is every body
+    for_bits4_gather(mask, lane == 0 ? C::NB : max_sub,                     // the world's subtree is every body
       [&](int k) { MP r; r.m = s.mass[k]; r.p = ld3(&s.x.a.xipos[3 * k]); return r; },
       [&](int, bool on, const MP& r) { float mk = on ? r.m : 0.0f; mm += mk; acc = acc + r.p * mk; });
     V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * lane]) : acc * (1.0f / mm);
@@ -450,8 +501,8 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   if (lane < C::NB) {
     int b = lane;
     const float* R = &s.x.a.ximat[9 * b];
-    V3 off = ld3(&s.x.a.xipos[3 * b]) - ld3(&s.com[3 * m.body_rootid[b]]);
-    float I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2], ms = s.mass[b];
+    V3 off = ld3(&s.x.a.xipos[3 * b]) - ld3(&s.com[3 * rb_misc.y]);
+    float I0 = asf(rb_inertia.x), I1 = asf(rb_inertia.y), I2 = asf(rb_inertia.z), ms = s.mass[b];
     float* ci = &s.x.a.cinert[10 * b];
     ci[0] = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2] + ms * (off.y * off.y + off.z * off.z);
     ci[1] = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5] + ms * (off.x * off.x + off.z * off.z);
@@ -463,8 +514,8 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   }
   // cdof: lane = dof
   if (lane < C::NV) {
-    int i = lane, j = m.dof_jntid[i], b = m.dof_bodyid[i], jt = m.dof_jtype[i], k = m.dof_k[i];
-    V3 off = ld3(&s.com[3 * m.dof_rootid[i]]) - ld3(&s.x.a.xanchor[3 * j]);
+    const int i = lane, j = rd_ids.x, b = rd_ids.y, jt = rd_ids.z, k = rd_ids.w;
+    V3 off = ld3(&s.com[3 * rd_masks.x]) - ld3(&s.x.a.xanchor[3 * j]);
     V3 ang, lin;
     if (jt == JNT_FREE) {
       if (k < 3) { ang = v3(0, 0, 0); lin = v3(k == 0, k == 1, k == 2); }
@@ -476,25 +527,29 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   for (int t = lane; t < C::NV * C::LD; t += 64) s.M[t] = 0.0f;
   WSYNC();
   // composite inertia: item (b, c) sums cinert over the subtree of b
-  for (int t = lane; t < C::NB * 10; t += 64) {
+#pragma unroll
+  for (int p = 0; p < NPASS_CRB; ++p) {
+    const int t = lane + 64 * p;
+    if (t >= C::NB * 10) continue;
     int b = t / 10, c = t - 10 * b;
-    unsigned mask = b == 0 ? 0u : m.body_submask[b];
+    unsigned mask = crb_mask[p];
     float acc = 0;
-    for_bits4_gather(mask, m.max_sub, [&](int k) { return s.x.a.cinert[10 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
+    for_bits4_gather(mask, max_sub, [&](int k) { return s.x.a.cinert[10 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
     s.x.a.crb[t] = acc;
   }
   WSYNC();
   if (lane < C::NV) {
     int i = lane;
     float f[6];
-    inert_mul(f, &s.x.a.crb[10 * m.dof_bodyid[i]], &s.cdof[6 * i]);
-    unsigned mask = m.dof_ancmask[i];
-    const float arma = mdl_armature<C>(m, s, i);
+    inert_mul(f, &s.x.a.crb[10 * rd_ids.y], &s.cdof[6 * i]);
+    unsigned mask = (unsigned)rd_masks.y;
+    float arma;
+    if constexpr (C::DREX) arma = s.dx_arma[i]; else arma = asf(rd_masks.w);
     // Exhausted masks store into the row's padding word M[i][NV] rather than being predicated off (a predicated store
     // drags its loads into the exec region, where they wait one by one).
     const int pad = i * C::LD + C::NV;
     struct C6 { float c[6]; };
-    for_bits4_gather(mask, m.max_chain,
+    for_bits4_gather(mask, max_chain,
       [&](int j) { C6 r;
 #pragma unroll
                    for (int k = 0; k < 6; ++k) r.c[k] = s.cdof[6 * j + k];
@@ -984,11 +1039,31 @@ __device__ __forceinline__ void motion_cross(float* o, const float* u, const flo
 struct Q6 { float qd; float c[6]; };      // one chain dof: its velocity and a spatial vector
 template <class C>
 __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
+  const int lr = lrec_lane(lane);
+  const int4 rb_misc = lrec(m, LQ_B_MISC, lr), rd_ids = lrec(m, LQ_D_IDS, lr), rd_masks = lrec(m, LQ_D_MASKS, lr);
+  const int4 rd_act = lrec(m, LQ_D_ACT, lr), rd_ctrl = lrec(m, LQ_D_CTRL, lr), rd_bias = lrec(m, LQ_D_BIAS, lr), rd_frc = lrec(m, LQ_D_FRC, lr);
+  const int max_sub = m.max_sub, max_chain = m.max_chain;
+  const float grav0 = m.gravity[0], grav1 = m.gravity[1], grav2 = m.gravity[2];
+  constexpr int NPASS_FRC = (C::NB * 6 + 63) / 64;
+  unsigned frc_mask[NPASS_FRC];        // subtree masks for the force sums below (see com_crb_mass)
+#pragma unroll
+  for (int p = 0; p < NPASS_FRC; ++p) {
+    const int bb = (lane + 64 * p) / 6;
+    const unsigned mb = (unsigned)__shfl(rb_misc.z, bb < C::NB ? bb : 0);     // unconditional: every source lane must be active
+    frc_mask[p] = bb >= C::NB ? 0u : mb;
+  }
+  const int site_b = lrec(m, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
+  int xfrc_b = 0, xfrc_root = 0; unsigned xfrc_dofs = 0u;
+  if constexpr (C::XFRC) {
+    xfrc_b = s.xfrc_body;
+    const int src = xfrc_b > 0 && xfrc_b < C::NB ? xfrc_b : 0;
+    xfrc_root = __shfl(rb_misc.y, src); xfrc_dofs = (unsigned)__shfl(rb_misc.w, src);
+  }
   // cvel[b] = sum over the dofs on b's chain of cdof*qvel
   if (lane < C::NB) {
-    unsigned mask = m.body_dofmask[lane];
+    unsigned mask = (unsigned)rb_misc.w;
     float v[6] = {0, 0, 0, 0, 0, 0};
-    for_bits4_gather(mask, m.max_chain,
+    for_bits4_gather(mask, max_chain,
       [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
                    for (int c = 0; c < 6; ++c) r.c[c] = s.cdof[6 * i + c];
@@ -1001,10 +1076,10 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   }
   // cdof_dot[i] = (velocity of the chain before dof i) x cdof[i]
   if (lane < C::NV) {
-    unsigned mask = m.dof_velmask[lane];
-    bool free_trans = (m.dof_jtype[lane] == JNT_FREE) && (m.dof_k[lane] < 3);
+    unsigned mask = (unsigned)rd_masks.z;
+    bool free_trans = (rd_ids.z == JNT_FREE) && (rd_ids.w < 3);
     float v[6] = {0, 0, 0, 0, 0, 0};
-    for_bits4_gather(mask, m.max_chain,
+    for_bits4_gather(mask, max_chain,
       [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
                    for (int c = 0; c < 6; ++c) r.c[c] = s.cdof[6 * i + c];
@@ -1020,16 +1095,16 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   WSYNC();
   // object velocity at every site, world frame (source of gyro / velocimeter / framelinvel / frameangvel sensors)
   if (lane < C::NS) {
-    int sb = m.site_bodyid[lane];
+    const int sb = site_b;
     V3 w = ld3(&s.x.a.cvel[6 * sb]), v = ld3(&s.x.a.cvel[6 * sb + 3]);
-    V3 off = ld3(&s.spos[3 * lane]) - ld3(&s.com[3 * m.body_rootid[sb]]);
+    V3 off = ld3(&s.spos[3 * lane]) - ld3(&s.com[3 * site_root]);
     st3(&s.sangvel[3 * lane], w); st3(&s.slinvel[3 * lane], v + cross(w, off));
   }
   // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)
   if (lane < C::NB) {
-    unsigned mask = m.body_dofmask[lane];
-    float a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-    for_bits4_gather(mask, m.max_chain,
+    unsigned mask = (unsigned)rb_misc.w;
+    float a[6] = {0, 0, 0, -grav0, -grav1, -grav2};
+    for_bits4_gather(mask, max_chain,
       [&](int i) { Q6 r; r.qd = s.qvel[i];
 #pragma unroll
                    for (int c = 0; c < 6; ++c) r.c[c] = s.x.a.cdofdot[6 * i + c];
@@ -1052,41 +1127,46 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     s.x.a.cfrc[6 * lane + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * lane + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * lane + 5] = f1[5] + tl.z;
   }
   WSYNC();
-  for (int t = lane; t < C::NB * 6; t += 64) {
+#pragma unroll
+  for (int p = 0; p < NPASS_FRC; ++p) {
+    const int t = lane + 64 * p;
+    if (t >= C::NB * 6) continue;
     int b = t / 6, c = t - 6 * b;
-    unsigned mask = m.body_submask[b];
+    unsigned mask = frc_mask[p];
     float acc = 0;
-    for_bits4_gather(mask, m.max_sub, [&](int k) { return s.x.a.cfrc[6 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
+    for_bits4_gather(mask, max_sub, [&](int k) { return s.x.a.cfrc[6 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
     s.x.a.cfrcsum[t] = acc;
   }
   WSYNC();
   float smooth = 0.0f;
   if (lane < C::NV) {
-    int i = lane, b = m.dof_bodyid[i];
+    int i = lane, b = rd_ids.y;
     float bias = 0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) bias += s.cdof[6 * i + c] * s.x.a.cfrcsum[6 * b + c];
     float passive = -s.damp[i] * qvel_i;
     // actuation: joint transmission, at most one actuator per dof (dof_act)
     float act = 0;
-    const int u = m.dof_act[i];
+    const int u = rd_act.x;
     if (u >= 0) {
-      float gear = m.actuator_gear[u];
-      float length = s.qpos[m.jnt_qposadr[m.dof_jntid[i]]] * gear, velocity = qvel_i * gear;
+      float gear = asf(rd_act.y);
+      float length = s.qpos[rd_act.z] * gear, velocity = qvel_i * gear;
       float ctrl = s.ctrl[u];
-      if (m.actuator_ctrllimited[u]) ctrl = clampf(ctrl, m.actuator_ctrlrange[2 * u], m.actuator_ctrlrange[2 * u + 1]);
-      float force = mdl_gain<C>(m, s, 3 * u) * ctrl + mdl_bias<C>(m, s, 3 * u) + mdl_bias<C>(m, s, 3 * u + 1) * length +
-                    mdl_bias<C>(m, s, 3 * u + 2) * velocity;
-      if (m.actuator_forcelimited[u]) force = clampf(force, m.actuator_forcerange[2 * u], m.actuator_forcerange[2 * u + 1]);
+      if (rd_act.w) ctrl = clampf(ctrl, asf(rd_ctrl.x), asf(rd_ctrl.y));
+      float gain0, bias0, bias1, bias2;
+      if constexpr (C::DREX) { gain0 = s.dx_gain[3 * u]; bias0 = s.dx_bias[3 * u]; bias1 = s.dx_bias[3 * u + 1]; bias2 = s.dx_bias[3 * u + 2]; }
+      else { gain0 = asf(rd_ctrl.z); bias0 = asf(rd_ctrl.w); bias1 = asf(rd_bias.x); bias2 = asf(rd_bias.y); }
+      float force = gain0 * ctrl + bias0 + bias1 * length + bias2 * velocity;
+      if (rd_bias.z) force = clampf(force, asf(rd_bias.w), asf(rd_frc.x));
       s.aforce[u] = force;
       act = gear * force;
     }
-    if (m.dof_afl[i]) act = clampf(act, m.dof_afrange[2 * i], m.dof_afrange[2 * i + 1]);
+    if (rd_frc.y) act = clampf(act, asf(rd_frc.z), asf(rd_frc.w));
     smooth = passive - bias + act;
     if constexpr (C::XFRC) {     // support.xfrc_accumulate: J(xipos[body])^T force
-      const int xb = s.xfrc_body;
-      if (xb > 0 && ((m.body_dofmask[xb] >> i) & 1)) {
-        V3 off = ld3(&s.x.a.xipos[3 * xb]) - ld3(&s.com[3 * m.body_rootid[xb]]);
+      const int xb = xfrc_b;
+      if (xb > 0 && ((xfrc_dofs >> i) & 1)) {
+        V3 off = ld3(&s.x.a.xipos[3 * xb]) - ld3(&s.com[3 * xfrc_root]);
         V3 jp = ld3(&s.cdof[6 * i + 3]) + cross(ld3(&s.cdof[6 * i]), off);
         smooth += jp.x * s.xfrc[0] + jp.y * s.xfrc[1] + jp.z * s.xfrc[2];
       }

@@ -1111,6 +1111,8 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(int, pair_b1) P(int, pair_b2) P(int, pair_root1) P(int, pair_root2) P(unsigned, pair_mask1) P(unsigned, pair_mask2)
   P(float, pair_tw) P(float, pair_incl) P(int, dof_rootid) P(int, dof_jtype) P(int, dof_k) P(int, dof_act) P(int, dof_afl)
   P(float, dof_afrange) P(int, body_jtype) P(int, body_qposadr) P(float, body_jpos) P(float, body_jaxis)
+  P(int4, lane_rec)
+  { int nrec = 0; m->find("lane_rec", &nrec); if (nrec != rsr::LQ_COUNT * 64 * 4) return fail(RSR_ERR_ARG, "blob field lane_rec has the wrong size (model.py lane_records vs enum LaneQuad)"); }
   P(float, hfield_size) P(float, hfield_data) P(int, hfield_nrow) P(int, hfield_ncol)
   P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
   if (dm.env_kind == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2) {

@@ -79,7 +79,9 @@ def model_fields(m: CompiledModel) -> Dict[str, np.ndarray]:
         f[k] = np.asarray(v)
     f["dims"] = np.array([m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.nsite,
                           int(m.arrays["eq_obj1id"].shape[0]), m.npair], dtype=np.int32)
-    f.update(topology_tables(m))
+    topo = topology_tables(m)
+    f.update(topo)
+    f["lane_rec"] = lane_records(m, topo)
     return f
 
 
@@ -127,6 +129,80 @@ def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np
             bj[b], bq[b], bjp[b], bja[b] = A["jnt_type"][j], A["jnt_qposadr"][j], A["jnt_pos"][j], A["jnt_axis"][j]
     out.update(body_jtype=bj, body_qposadr=bq, body_jpos=bjp, body_jaxis=bja)
     return out
+
+
+# quads (16-byte groups) of the per-lane records; keep in step with enum LaneQuad in csrc/rsr_device.hpp
+LANE_QUADS = 23
+
+
+def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
+    """Per-lane constant records for the tree stages of the kernel: int32 [LANE_QUADS][64][4] (floats stored by bit pattern).
+
+    In the kernel lane l plays body l, joint l, geom l, site l and dof l.  Fetching that lane's model constants from
+    the per-field tables costs a dependent chain of scalar pointer load + vector load per field, a few hundred cycles
+    each, in every substep.  Here everything a role needs is gathered (indirections resolved on the host) into quads
+    laid out [quad][lane], so a stage issues all of its constant loads back to back, coalesced, and waits once.
+    Lanes beyond a role's count hold zeros.  Layout (i = integer word):
+      body : 0 (i parentid, i depth, i jtype, i qposadr)  1 (pos xyz, qpos0[qposadr])  2 quat  3 (jpos xyz, jaxis x)
+             4 (jaxis yz, ipos xy)  5 iquat  6 (ipos z, i rootid, i submask, i dofmask)  7 (inertia xyz, 0)
+      joint: 8 (i bodyid, i parent of that body, i type, 0)  9 body_quat[bodyid]  10 (body_pos[bodyid] xyz, jnt_pos x)
+             11 (jnt_pos yz, jnt_axis xy)  12 (jnt_axis z, 0, 0, 0)
+      geom : 13 (i bodyid, pos xyz)  14 quat            site : 15 (i bodyid, pos xyz)  16 quat
+      dof  : 17 (i jntid, i bodyid, i jtype, i k)  18 (i rootid, i ancmask, i velmask, armature)
+             19 (i actuator or -1, gear, i qposadr of the joint, i ctrllimited)  20 (ctrl lo, ctrl hi, gainprm0, biasprm0)
+             21 (biasprm1, biasprm2, i forcelimited, force lo)  22 (force hi, i actfrclimited, actfrc lo, actfrc hi)
+    """
+    A = m.arrays
+    rec = np.zeros((LANE_QUADS, 64, 4), dtype=np.int32)
+    fv = rec.view(np.float32)
+    if max(m.nbody, m.njnt, m.ngeom, m.nsite, m.nv) > 64:
+        raise ValueError("lane records need at most 64 bodies / joints / geoms / sites / dofs")
+    u32 = lambda x: np.uint32(int(x) & 0xFFFFFFFF).view(np.int32)
+    for b in range(m.nbody):
+        qa = int(topo["body_qposadr"][b])
+        rec[0, b] = [A["body_parentid"][b], topo["body_depth"][b], topo["body_jtype"][b], qa]
+        fv[1, b] = [*A["body_pos"][b], A["qpos0"][qa] if topo["body_jtype"][b] >= 0 else 0.0]
+        fv[2, b] = A["body_quat"][b]
+        fv[3, b] = [*topo["body_jpos"][b], topo["body_jaxis"][b][0]]
+        fv[4, b] = [topo["body_jaxis"][b][1], topo["body_jaxis"][b][2], A["body_ipos"][b][0], A["body_ipos"][b][1]]
+        fv[5, b] = A["body_iquat"][b]
+        fv[6, b, 0] = A["body_ipos"][b][2]
+        rec[6, b, 1:] = [A["body_rootid"][b], u32(topo["body_submask"][b]), u32(topo["body_dofmask"][b])]
+        fv[7, b, :3] = A["body_inertia"][b]
+    for j in range(m.njnt):
+        jb = int(A["jnt_bodyid"][j])
+        rec[8, j] = [jb, A["body_parentid"][jb], A["jnt_type"][j], 0]
+        fv[9, j] = A["body_quat"][jb]
+        fv[10, j] = [*A["body_pos"][jb], A["jnt_pos"][j][0]]
+        fv[11, j] = [A["jnt_pos"][j][1], A["jnt_pos"][j][2], A["jnt_axis"][j][0], A["jnt_axis"][j][1]]
+        fv[12, j, 0] = A["jnt_axis"][j][2]
+    for g in range(m.ngeom):
+        rec[13, g, 0] = A["geom_bodyid"][g]
+        fv[13, g, 1:] = A["geom_pos"][g]
+        fv[14, g] = A["geom_quat"][g]
+    for k in range(m.nsite):
+        rec[15, k, 0] = A["site_bodyid"][k]
+        fv[15, k, 1:] = A["site_pos"][k]
+        fv[16, k] = A["site_quat"][k]
+    for i in range(m.nv):
+        jid = int(A["dof_jntid"][i])
+        rec[17, i] = [jid, A["dof_bodyid"][i], topo["dof_jtype"][i], topo["dof_k"][i]]
+        rec[18, i, :3] = [topo["dof_rootid"][i], u32(topo["dof_ancmask"][i]), u32(topo["dof_velmask"][i])]
+        fv[18, i, 3] = A["dof_armature"][i]
+        u = int(topo["dof_act"][i])
+        rec[19, i, 0] = u
+        rec[19, i, 2] = A["jnt_qposadr"][jid]
+        if u >= 0:
+            fv[19, i, 1] = A["actuator_gear"][u] if np.ndim(A["actuator_gear"][u]) == 0 else A["actuator_gear"][u][0]
+            rec[19, i, 3] = A["actuator_ctrllimited"][u]
+            fv[20, i] = [*A["actuator_ctrlrange"][u], A["actuator_gainprm"][u][0], A["actuator_biasprm"][u][0]]
+            fv[21, i, :2] = A["actuator_biasprm"][u][1:3]
+            rec[21, i, 2] = A["actuator_forcelimited"][u]
+            fv[21, i, 3] = A["actuator_forcerange"][u][0]
+            fv[22, i, 0] = A["actuator_forcerange"][u][1]
+        rec[22, i, 1] = topo["dof_afl"][i]
+        fv[22, i, 2:] = topo["dof_afrange"][i]
+    return rec
 
 
 def topology_tables(m: CompiledModel) -> Dict[str, np.ndarray]:
