@@ -340,7 +340,9 @@ template <class C> __device__ __forceinline__ float mdl_bias(const DModel& m, co
 // flight together, one wait.  Lanes past a role's count read zeros.
 enum LaneQuad { LQ_B_IDS = 0, LQ_B_POS, LQ_B_QUAT, LQ_B_JPOS, LQ_B_JAX, LQ_B_IQUAT, LQ_B_MISC, LQ_B_INERTIA,
                 LQ_J_IDS, LQ_J_BQUAT, LQ_J_BPOS, LQ_J_POSAX, LQ_J_AX, LQ_G_POS, LQ_G_QUAT, LQ_S_POS, LQ_S_QUAT,
-                LQ_D_IDS, LQ_D_MASKS, LQ_D_ACT, LQ_D_CTRL, LQ_D_BIAS, LQ_D_FRC, LQ_COUNT };
+                LQ_D_IDS, LQ_D_MASKS, LQ_D_ACT, LQ_D_CTRL, LQ_D_BIAS, LQ_D_FRC,
+                LQ_F_0, LQ_F_1, LQ_F_2, LQ_L_0, LQ_L_1, LQ_L_2, LQ_L_3, LQ_P_0, LQ_P_1, LQ_P_2, LQ_P_3, LQ_P_4, LQ_P_5,
+                LQ_E_0, LQ_E_1, LQ_E_2, LQ_E_3, LQ_E_4, LQ_COUNT };
 __device__ __forceinline__ int4 lrec(const DModel& m, int quad, int lane) { return m.lane_rec[quad * 64 + lane]; }
 // The lane index a stage passes to lrec: `lane` plus a zero the optimiser cannot see through.  The records are loop
 // invariant, and hoisted out of the substep loop they would stay live across the solver, where every register is taken:
@@ -971,23 +973,26 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane 
   CPts pts; pts.cnt = 0;
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
+  const int lr = lrec_lane(lane);
+  const int4 rp0 = lrec(m, LQ_P_0, lr), rp1 = lrec(m, LQ_P_1, lr), rp2 = lrec(m, LQ_P_2, lr);
   if (lane < C::NP) {
-    int p = lane, g1 = m.pair_geom1[p], g2 = m.pair_geom2[p], kind = m.pair_kind[p];
-    incl = m.pair_incl[p];
+    const int g1 = rp0.x, g2 = rp0.y, kind = rp0.z;
+    incl = asf(rp0.w);
+    const V3 size1 = v3_xyz(rp1), size2 = v3_xyz(rp2);
     V3 p1 = ld3(&s.x.a.gpos[3 * g1]), p2 = ld3(&s.x.a.gpos[3 * g2]);
-    if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, &s.x.a.gmat[9 * g1], p2, &s.x.a.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), pts, job);
+    if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, &s.x.a.gmat[9 * g1], p2, &s.x.a.gmat[9 * g2], size2, pts, job);
     else if (kind == PAIR_BOX_BOX)
-      box_box_sat(p1, &s.x.a.gmat[9 * g1], ld3(&m.geom_size[3 * g1]), p2, &s.x.a.gmat[9 * g2], ld3(&m.geom_size[3 * g2]), pts, job);
+      box_box_sat(p1, &s.x.a.gmat[9 * g1], size1, p2, &s.x.a.gmat[9 * g2], size2, pts, job);
     else if (kind == PAIR_PLANE_SPHERE) {
       V3 n = col(&s.x.a.gmat[9 * g1], 2);
-      float r = m.geom_size[3 * g2];
+      float r = size2.x;
       float dist = dot(p2 - p1, n) - r;
       pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;
     }
     if constexpr (C::HFIELD) {
       if (kind == PAIR_HFIELD_SPHERE) {
         float dist; V3 pos, n;
-        if (hfield_sphere(m, p1, &s.x.a.gmat[9 * g1], p2, m.geom_size[3 * g2], dist, pos, n)) { pts.n = n; pts.dist[0] = dist; pts.pos[0] = pos; pts.cnt = 1; }
+        if (hfield_sphere(m, p1, &s.x.a.gmat[9 * g1], p2, size2.x, dist, pos, n)) { pts.n = n; pts.dist[0] = dist; pts.pos[0] = pos; pts.cnt = 1; }
       }
     }
   }
@@ -1184,7 +1189,9 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
 // Row = base[bn] + mu * base[bk] (mu = 0 and bk = bn for the sparse rows).
 struct RowRegs { float aref, D, R, floss, mu; int bn, bk; };
 
-__device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const float* si, float pos, float& k, float& b, float& imp) {
+struct Solimp { float v[5]; };
+__device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const Solimp& sip, float pos, float& k, float& b, float& imp) {
+  const float* si = sip.v;
   float timeconst = sr0, dampratio = sr1;
   if (!m.disable_refsafe) timeconst = fmaxf(timeconst, 2.0f * m.timestep);
   float dmin = clampf(si[0], RSR_MINIMP, RSR_MAXIMP), dmax = clampf(si[1], RSR_MINIMP, RSR_MAXIMP);
@@ -1213,17 +1220,20 @@ template <class C>
 __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
                                int& nbase_out PROF_ARG) {
   constexpr int LD = C::LDJ;      // every LD below strides the Jacobian
-  // active joint limits, compacted in joint order
+  const int lr = lrec_lane(lane);
+  const int4 rl0 = lrec(m, LQ_L_0, lr), rl1 = lrec(m, LQ_L_1, lr);
+  const int4 re0 = lrec(m, LQ_E_0, lr), re1 = lrec(m, LQ_E_1, lr), re2 = lrec(m, LQ_E_2, lr), re3 = lrec(m, LQ_E_3, lr), re4 = lrec(m, LQ_E_4, lr);
+  const int4 rf0 = lrec(m, LQ_F_0, lr), rf1 = lrec(m, LQ_F_1, lr), rf2 = lrec(m, LQ_F_2, lr);
+  // active joint limits, compacted in slot order (slot = index into limit_jnts; its constants are record LQ_L_*[slot])
   int lim_active = 0;
   if (lane < C::NL) {
-    int j = m.limit_jnts[lane];
-    float q = s.qpos[m.jnt_qposadr[j]];
-    float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
-    lim_active = (fminf(dmin, dmax) - m.jnt_margin[j]) < 0.0f;
+    float q = s.qpos[rl0.x];
+    float dmin = q - asf(rl0.z), dmax = asf(rl0.w) - q;
+    lim_active = (fminf(dmin, dmax) - asf(rl1.x)) < 0.0f;
   }
   unsigned long long bal = __ballot(lim_active);
   int nl = __popcll(bal);
-  if (lim_active) s.lim_jnt[__popcll(bal & ((1ull << lane) - 1ull))] = m.limit_jnts[lane];
+  if (lim_active) s.lim_jnt[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
   const int r_fric = C::NEQ, r_lim = C::NEQ + C::NF, r_con = r_lim + nl;
   const int ncon = s.ncon;
   const int nefc = r_con + C::NPYR * ncon;
@@ -1234,32 +1244,35 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   if (lane < 4) { s.bval[C::NBASE + lane] = 0.0f; s.bmu[C::NBASE + lane] = 0.0f; }
   for (int t = lane; t < r_con; t += 64) s.bmu[t] = 0.0f;
   WSYNC();
-  if (lane < C::NEQ && m.eq_active0[lane]) {
-    int e = lane, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
-    float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j2]) : 0.0f;
-    const float* dt = &m.eq_data[5 * e];
-    float deriv = dt[1] + dif * (2.0f * dt[2] + dif * (3.0f * dt[3] + dif * 4.0f * dt[4]));
-    if (j2 >= 0) s.x.b.J[e * LD + m.jnt_dofadr[j2]] = -deriv;
-    s.x.b.J[e * LD + m.jnt_dofadr[j1]] = 1.0f;
+  // equality e = lane (joint coupling): dif = qpos[j2] - qpos0[j2], polynomial data[0..4]
+  float eq_dif = 0.0f;
+  if (lane < C::NEQ && re1.x) eq_dif = s.qpos[re1.y] - mdl_qpos0<C>(m, s, re1.y);
+  if (lane < C::NEQ && re0.x) {
+    const int e = lane;
+    float deriv = asf(re2.y) + eq_dif * (2.0f * asf(re2.z) + eq_dif * (3.0f * asf(re2.w) + eq_dif * 4.0f * asf(re3.x)));
+    if (re1.x) s.x.b.J[e * LD + re1.z] = -deriv;
+    s.x.b.J[e * LD + re0.z] = 1.0f;
   }
-  if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + m.fric_dofs[lane]] = 1.0f; s.sdof[r_fric + lane] = m.fric_dofs[lane]; }
+  if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + rf0.x] = 1.0f; s.sdof[r_fric + lane] = rf0.x; }
   if (lane < nl) {
-    int j = s.lim_jnt[lane];
-    float q = s.qpos[m.jnt_qposadr[j]];
-    float dmin = q - m.jnt_range[2 * j], dmax = m.jnt_range[2 * j + 1] - q;
-    s.x.b.J[(r_lim + lane) * LD + m.jnt_dofadr[j]] = dmin < dmax ? 1.0f : -1.0f;
-    s.sdof[r_lim + lane] = m.jnt_dofadr[j];
+    const int sl = s.lim_jnt[lane];
+    const int4 q0 = lrec(m, LQ_L_0, sl);
+    float q = s.qpos[q0.x];
+    float dmin = q - asf(q0.z), dmax = asf(q0.w) - q;
+    s.x.b.J[(r_lim + lane) * LD + q0.y] = dmin < dmax ? 1.0f : -1.0f;
+    s.sdof[r_lim + lane] = q0.y;
   }
   PROF(PS_X3)
   // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
     int p = s.cpair[c];
+    const int4 rp3 = lrec(m, LQ_P_3, p);
     V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
     make_frame(n, nn, t1, t2);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
-    float in1 = ((m.pair_mask1[p] >> i) & 1) ? 1.0f : 0.0f, in2 = ((m.pair_mask2[p] >> i) & 1) ? 1.0f : 0.0f;
-    V3 o1 = pos - ld3(&s.com[3 * m.pair_root1[p]]), o2 = pos - ld3(&s.com[3 * m.pair_root2[p]]);
+    float in1 = (((unsigned)rp3.x >> i) & 1) ? 1.0f : 0.0f, in2 = (((unsigned)rp3.y >> i) & 1) ? 1.0f : 0.0f;
+    V3 o1 = pos - ld3(&s.com[3 * rp3.z]), o2 = pos - ld3(&s.com[3 * rp3.w]);
     V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
     V3 jr = ang * (in2 - in1);
     float* Jr = &s.x.b.J[(r_con + C::NBC * c) * LD + i];
@@ -1270,10 +1283,11 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   // friction coefficient of each contact base row (normal: unused)
   for (int t = lane; t < ncon * C::NBC; t += 64) {
     int c = t / C::NBC, k = t - c * C::NBC;
-    int p = s.cpair[c], g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-    float f0 = fmaxf(s.fric[3 * g1], s.fric[3 * g2]), f1 = fmaxf(s.fric[3 * g1 + 1], s.fric[3 * g2 + 1]);
-    int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
-    if (pr1 != pr2) { int gw = pr1 > pr2 ? g1 : g2; f0 = s.fric[3 * gw]; f1 = s.fric[3 * gw + 1]; }
+    int p = s.cpair[c];
+    const int4 rp0 = lrec(m, LQ_P_0, p), rp2 = lrec(m, LQ_P_2, p);
+    const int g1 = rp0.x, g2 = rp0.y, rule = rp2.w;       // rule: 0 = max of the two geoms, 1 / 2 = the higher-priority geom's
+    float a0 = s.fric[3 * g1], a1 = s.fric[3 * g1 + 1], b0 = s.fric[3 * g2], b1 = s.fric[3 * g2 + 1];
+    float f0 = rule == 0 ? fmaxf(a0, b0) : (rule == 1 ? a0 : b0), f1 = rule == 0 ? fmaxf(a1, b1) : (rule == 1 ? a1 : b1);
     s.bmu[r_con + t] = k == 0 ? 0.0f : (k == 3 ? f1 : f0);
   }
   WSYNC();
@@ -1284,34 +1298,38 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
     int r = lane + 64 * ch;
     RowRegs o{0.0f, 0.0f, 1.0f, -1.0f, 0.0f, C::NBASE, C::NBASE};
     if (r < nefc) {
-      float pos = 0, invw = 0, sr0, sr1, fl = -1.0f; const float* si;
+      float pos = 0, invw = 0, sr0, sr1, fl = -1.0f; Solimp si;
       o.bn = r; o.bk = r;
-      if (r < r_fric) {
-        int e = r, j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
-        float dif = j2 >= 0 ? s.qpos[m.jnt_qposadr[j2]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j2]) : 0.0f;
-        const float* dt = &m.eq_data[5 * e];
-        float poly = dt[0] + dif * (dt[1] + dif * (dt[2] + dif * (dt[3] + dif * dt[4])));
-        pos = s.qpos[m.jnt_qposadr[j1]] - mdl_qpos0<C>(m, s, m.jnt_qposadr[j1]) - poly;
-        invw = m.dof_invweight0[m.jnt_dofadr[j1]] + (j2 >= 0 ? m.dof_invweight0[m.jnt_dofadr[j2]] : 0.0f);
-        sr0 = m.eq_solref[2 * e]; sr1 = m.eq_solref[2 * e + 1]; si = &m.eq_solimp[5 * e];
-      } else if (r < r_lim) {
-        int i = m.fric_dofs[r - r_fric];
-        invw = m.dof_invweight0[i]; sr0 = m.dof_solref[2 * i]; sr1 = m.dof_solref[2 * i + 1]; si = &m.dof_solimp[5 * i];
-        fl = s.floss[i];
-      } else if (r < r_con) {
-        int j = s.lim_jnt[r - r_lim];
-        float q = s.qpos[m.jnt_qposadr[j]];
-        pos = fminf(q - m.jnt_range[2 * j], m.jnt_range[2 * j + 1] - q) - m.jnt_margin[j];
-        invw = m.dof_invweight0[m.jnt_dofadr[j]]; sr0 = m.jnt_solref[2 * j]; sr1 = m.jnt_solref[2 * j + 1]; si = &m.jnt_solimp[5 * j];
+      if (r < r_fric) {                      // equality row r = lane (first chunk)
+        float poly = asf(re2.x) + eq_dif * (asf(re2.y) + eq_dif * (asf(re2.z) + eq_dif * (asf(re2.w) + eq_dif * asf(re3.x))));
+        pos = s.qpos[re0.y] - mdl_qpos0<C>(m, s, re0.y) - poly;
+        invw = asf(re0.w);
+        sr0 = asf(re3.y); sr1 = asf(re3.z);
+        si.v[0] = asf(re3.w); si.v[1] = asf(re4.x); si.v[2] = asf(re4.y); si.v[3] = asf(re4.z); si.v[4] = asf(re4.w);
+      } else if (r < r_lim) {                // friction row: slot r - r_fric
+        const int sl = r - r_fric;
+        const int4 q0 = lrec(m, LQ_F_0, sl), q1 = lrec(m, LQ_F_1, sl), q2 = lrec(m, LQ_F_2, sl);
+        invw = asf(q0.y); sr0 = asf(q0.z); sr1 = asf(q0.w);
+        si.v[0] = asf(q1.x); si.v[1] = asf(q1.y); si.v[2] = asf(q1.z); si.v[3] = asf(q1.w); si.v[4] = asf(q2.x);
+        fl = s.floss[q0.x];
+      } else if (r < r_con) {                // active limit: slot from the compaction
+        const int sl = s.lim_jnt[r - r_lim];
+        const int4 q0 = lrec(m, LQ_L_0, sl), q1 = lrec(m, LQ_L_1, sl), q2 = lrec(m, LQ_L_2, sl), q3 = lrec(m, LQ_L_3, sl);
+        float q = s.qpos[q0.x];
+        pos = fminf(q - asf(q0.z), asf(q0.w) - q) - asf(q1.x);
+        invw = asf(q1.y); sr0 = asf(q1.z); sr1 = asf(q1.w);
+        si.v[0] = asf(q2.x); si.v[1] = asf(q2.y); si.v[2] = asf(q2.z); si.v[3] = asf(q2.w); si.v[4] = asf(q3.x);
       } else {
         int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c];
-        pos = s.cdist[c] - m.pair_incl[p];
+        const int4 q0 = lrec(m, LQ_P_0, p), q1 = lrec(m, LQ_P_1, p), q4 = lrec(m, LQ_P_4, p), q5 = lrec(m, LQ_P_5, p);
+        pos = s.cdist[c] - asf(q0.w);
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];
         o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
-        float tw = m.pair_tw[p];
+        float tw = asf(q1.w);
         invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / m.impratio;
-        sr0 = m.pair_solref[2 * p]; sr1 = m.pair_solref[2 * p + 1]; si = &m.pair_solimp[5 * p];
+        sr0 = asf(q4.x); sr1 = asf(q4.y);
+        si.v[0] = asf(q4.z); si.v[1] = asf(q4.w); si.v[2] = asf(q5.x); si.v[3] = asf(q5.y); si.v[4] = asf(q5.z);
       }
       float k, b, imp;
       kbi(m, sr0, sr1, si, pos, k, b, imp);

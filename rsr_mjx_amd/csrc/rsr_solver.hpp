@@ -507,6 +507,8 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
 // integrate one substep after forward(): implicitfast / Euler, then _advance
 template <class C>
 __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
+  const int lr = lrec_lane(lane);
+  const int4 rj_ids = lrec(m, LQ_J_IDS, lr), rj_ax = lrec(m, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
   float qacc = f.qacc;
   bool implicit = m.integrator == INT_IMPLICITFAST;
   if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
@@ -525,9 +527,9 @@ __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane,
   if (lane < C::NV) s.qvel[lane] += qacc * m.timestep;
   WSYNC();
   if (lane < C::NJ) {
-    int j = lane, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    const int qa = rj_ax.y, da = rj_ax.z;
     float dt = m.timestep;
-    if (m.jnt_type[j] == JNT_FREE) {
+    if (rj_ids.z == JNT_FREE) {
       s.qpos[qa] += dt * s.qvel[da]; s.qpos[qa + 1] += dt * s.qvel[da + 1]; s.qpos[qa + 2] += dt * s.qvel[da + 2];
       V3 w = ld3(&s.qvel[da + 3]);
       float n = sqrtf(dot(w, w));

@@ -132,7 +132,7 @@ def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np
 
 
 # quads (16-byte groups) of the per-lane records; keep in step with enum LaneQuad in csrc/rsr_device.hpp
-LANE_QUADS = 23
+LANE_QUADS = 41
 
 
 def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
@@ -151,6 +151,14 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
       dof  : 17 (i jntid, i bodyid, i jtype, i k)  18 (i rootid, i ancmask, i velmask, armature)
              19 (i actuator or -1, gear, i qposadr of the joint, i ctrllimited)  20 (ctrl lo, ctrl hi, gainprm0, biasprm0)
              21 (biasprm1, biasprm2, i forcelimited, force lo)  22 (force hi, i actfrclimited, actfrc lo, actfrc hi)
+    and, indexed by the constraint-side roles (friction row l, limit slot l, geom pair l, equality l):
+      fric : 23 (i dof, invweight0, solref 0 1)  24 (solimp 0..3)  25 (solimp 4, 0, 0, 0)
+      limit: 26 (i qposadr, i dofadr, range lo hi)  27 (margin, invweight0, solref 0 1)  28 (solimp 0..3)  29 (solimp 4, i joint, 0, 0)
+      pair : 30 (i geom1, i geom2, i kind, margin - gap)  31 (size[geom1] xyz, tw)  32 (size[geom2] xyz, i friction rule: 0 max,
+             1 geom1's, 2 geom2's)  33 (i mask1, i mask2, i root1, i root2)  34 (solref 0 1, solimp 0 1)  35 (solimp 2 3 4, 0)
+      eq   : 36 (i active, i qposadr1, i dofadr1, invweight0 sum)  37 (i has obj2, i qposadr2, i dofadr2, 0)  38 (data 0..3)
+             39 (data 4, solref 0 1, solimp 0)  40 (solimp 1..4)
+    The joint quad 12 also carries (jnt_axis z, i qposadr, i dofadr, 0) for the integrator.
     """
     A = m.arrays
     rec = np.zeros((LANE_QUADS, 64, 4), dtype=np.int32)
@@ -176,6 +184,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
         fv[10, j] = [*A["body_pos"][jb], A["jnt_pos"][j][0]]
         fv[11, j] = [A["jnt_pos"][j][1], A["jnt_pos"][j][2], A["jnt_axis"][j][0], A["jnt_axis"][j][1]]
         fv[12, j, 0] = A["jnt_axis"][j][2]
+        rec[12, j, 1:3] = [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
     for g in range(m.ngeom):
         rec[13, g, 0] = A["geom_bodyid"][g]
         fv[13, g, 1:] = A["geom_pos"][g]
@@ -202,6 +211,46 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
             fv[22, i, 0] = A["actuator_forcerange"][u][1]
         rec[22, i, 1] = topo["dof_afl"][i]
         fv[22, i, 2:] = topo["dof_afrange"][i]
+    if max(len(topo["fric_dofs"]), len(topo["limit_jnts"]), m.npair, int(A["eq_obj1id"].shape[0])) > 64:
+        raise ValueError("lane records need at most 64 friction rows / limited joints / geom pairs / equalities")
+    for l, i in enumerate(topo["fric_dofs"]):
+        i = int(i)
+        rec[23, l, 0] = i
+        fv[23, l, 1:] = [A["dof_invweight0"][i], *A["dof_solref"][i]]
+        fv[24, l] = A["dof_solimp"][i][:4]
+        fv[25, l, 0] = A["dof_solimp"][i][4]
+    for l, j in enumerate(topo["limit_jnts"]):
+        j = int(j)
+        rec[26, l, :2] = [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
+        fv[26, l, 2:] = A["jnt_range"][j]
+        fv[27, l] = [A["jnt_margin"][j], A["dof_invweight0"][int(A["jnt_dofadr"][j])], *A["jnt_solref"][j]]
+        fv[28, l] = A["jnt_solimp"][j][:4]
+        fv[29, l, 0] = A["jnt_solimp"][j][4]
+        rec[29, l, 1] = j
+    for q in range(m.npair):
+        g1, g2 = int(A["pair_geom1"][q]), int(A["pair_geom2"][q])
+        rec[30, q, :3] = [g1, g2, A["pair_kind"][q]]
+        fv[30, q, 3] = topo["pair_incl"][q]
+        fv[31, q] = [*A["geom_size"][g1], topo["pair_tw"][q]]
+        fv[32, q, :3] = A["geom_size"][g2]
+        p1, p2 = int(A["geom_priority"][g1]), int(A["geom_priority"][g2])
+        rec[32, q, 3] = 0 if p1 == p2 else (1 if p1 > p2 else 2)
+        rec[33, q] = [topo["pair_mask1"][q], topo["pair_mask2"][q], topo["pair_root1"][q], topo["pair_root2"][q]]
+        fv[34, q] = [*A["pair_solref"][q], *A["pair_solimp"][q][:2]]
+        fv[35, q, :3] = A["pair_solimp"][q][2:5]
+    for e in range(int(A["eq_obj1id"].shape[0])):
+        j1, j2 = int(A["eq_obj1id"][e]), int(A["eq_obj2id"][e])
+        d1 = int(A["jnt_dofadr"][j1])
+        invw = float(np.float32(A["dof_invweight0"][d1]))
+        rec[36, e, :3] = [A["eq_active0"][e], A["jnt_qposadr"][j1], d1]
+        if j2 >= 0:
+            d2 = int(A["jnt_dofadr"][j2])
+            invw = float(np.float32(invw) + np.float32(A["dof_invweight0"][d2]))     # the kernel's fp32 sum
+            rec[37, e, :3] = [1, A["jnt_qposadr"][j2], d2]
+        fv[36, e, 3] = invw
+        fv[38, e] = A["eq_data"][e][:4]
+        fv[39, e] = [A["eq_data"][e][4], *A["eq_solref"][e], A["eq_solimp"][e][0]]
+        fv[40, e] = A["eq_solimp"][e][1:5]
     return rec
 
 
