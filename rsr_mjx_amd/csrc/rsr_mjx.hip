@@ -932,8 +932,24 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------- launchers of the Go2 kernels
+// The Go2 kernels are built as a translation unit of their own (this file with -DRSR_TU_GO2 -fno-slp-vectorize, see
+// rsr_mjx_amd/build.py): the SLP vectoriser's packed-fp32 pairing costs them ~3% while it gains the Airbot kernels ~1%.
+// Kernel templates are instantiated where they are launched, so each unit compiles only its own kernels.
+void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+#ifdef RSR_TU_GO2
+void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
+  hipLaunchKernelGGL((go2_reset_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+}
+void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
+  hipLaunchKernelGGL((go2_step_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+}
+#endif
+
 }  // namespace rsr
 
+#ifndef RSR_TU_GO2
 // =====================================================================================
 // host side: C ABI
 // =====================================================================================
@@ -1222,8 +1238,7 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   a.keys = keys;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
-    hipLaunchKernelGGL((rsr::go2_reset_kernel<rsr::Go2Dims>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::Go2Dims>), st, b->dmodel,
-                       b->model->layout, a);
+    rsr::launch_go2_reset(b->n, st, b->dmodel, b->model->layout, a);
   else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
     hipLaunchKernelGGL((rsr::reset_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                        b->dmodel, b->model->layout, a);
@@ -1241,8 +1256,7 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   a.action = action;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
-    hipLaunchKernelGGL((rsr::go2_step_kernel<rsr::Go2Dims>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::Go2Dims>), st, b->dmodel,
-                       b->model->layout, a);
+    rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a);
   else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
     hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                        b->dmodel, b->model->layout, a);
@@ -1324,3 +1338,4 @@ extern "C" int rsr_timing_end(rsr_batch* b, void* hip_stream, float* total_ms, i
   b->timing = false;
   return RSR_OK;
 }
+#endif  // !RSR_TU_GO2

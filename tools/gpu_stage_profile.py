@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "rsr_mjx_amd", "csrc")
 PROF = os.path.join(CSRC, "librsrmjx_prof.so")
 if not os.path.exists(PROF) or "--rebuild" in sys.argv:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRSR_PROFILE",
-                           "-o", PROF, os.path.join(CSRC, "rsr_mjx.hip")])
+    from rsr_mjx_amd.build import compile_lib
+    compile_lib(PROF, extra_flags=["-DRSR_PROFILE"])
 os.environ["RSR_MJX_LIB"] = PROF
 import numpy as np
 import torch
