@@ -68,3 +68,52 @@ def test_euler_and_inertia_helpers():
     np.testing.assert_allclose(w, [3, 2, 1])
     R = mjcf.quat_to_mat(iq)
     np.testing.assert_allclose(R @ np.diag(w) @ R.T, np.diag([1.0, 3.0, 2.0]), atol=1e-12)
+
+
+def test_lane_records_restate_the_model_tables(cube_model):
+    """model.lane_records: the per-lane quads the kernel's stages fetch must carry exactly what the per-field tables hold
+    (layout documented in lane_records; the device side is enum LaneQuad in csrc/rsr_device.hpp, whose count the library
+    checks against the blob at rsr_model_create)."""
+    import re
+    from rsr_mjx_amd.model import LANE_QUADS, lane_records, topology_tables
+    m = cube_model
+    A, topo = m.arrays, topology_tables(m)
+    rec = lane_records(m, topo)
+    fv = rec.view(np.float32)
+    assert rec.shape == (LANE_QUADS, 64, 4) and rec.dtype == np.int32
+    f32 = lambda x: np.asarray(x, dtype=np.float32)
+    for b in range(m.nbody):
+        assert list(rec[0, b]) == [A["body_parentid"][b], topo["body_depth"][b], topo["body_jtype"][b], topo["body_qposadr"][b]]
+        np.testing.assert_array_equal(fv[2, b], f32(A["body_quat"][b]))
+        np.testing.assert_array_equal([fv[4, b, 2], fv[4, b, 3], fv[6, b, 0]], f32(A["body_ipos"][b]))
+        assert rec[6, b, 1] == A["body_rootid"][b] and np.uint32(rec[6, b, 2]) == np.uint32(topo["body_submask"][b])
+        np.testing.assert_array_equal(fv[7, b, :3], f32(A["body_inertia"][b]))
+    for j in range(m.njnt):
+        jb = int(A["jnt_bodyid"][j])
+        assert list(rec[8, j, :3]) == [jb, A["body_parentid"][jb], A["jnt_type"][j]]
+        np.testing.assert_array_equal([fv[11, j, 2], fv[11, j, 3], fv[12, j, 0]], f32(A["jnt_axis"][j]))
+        assert list(rec[12, j, 1:3]) == [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
+    for i in range(m.nv):
+        u = int(topo["dof_act"][i])
+        assert rec[19, i, 0] == u and np.uint32(rec[18, i, 1]) == np.uint32(topo["dof_ancmask"][i])
+        if u >= 0:
+            np.testing.assert_array_equal([fv[20, i, 2], fv[20, i, 3], fv[21, i, 0], fv[21, i, 1]],
+                                          f32([A["actuator_gainprm"][u][0], *A["actuator_biasprm"][u][:3]]))
+    for l, j in enumerate(topo["limit_jnts"]):
+        assert list(rec[26, l, :2]) == [A["jnt_qposadr"][j], A["jnt_dofadr"][j]] and rec[29, l, 1] == j
+        np.testing.assert_array_equal(fv[26, l, 2:], f32(A["jnt_range"][j]))
+        np.testing.assert_array_equal([*fv[28, l], fv[29, l, 0]], f32(A["jnt_solimp"][j]))
+    for q in range(m.npair):
+        g1, g2 = int(A["pair_geom1"][q]), int(A["pair_geom2"][q])
+        assert list(rec[30, q, :3]) == [g1, g2, A["pair_kind"][q]]
+        np.testing.assert_array_equal(fv[32, q, :3], f32(A["geom_size"][g2]))
+        p1, p2 = A["geom_priority"][g1], A["geom_priority"][g2]
+        assert rec[32, q, 3] == (0 if p1 == p2 else (1 if p1 > p2 else 2))
+        np.testing.assert_array_equal([*fv[34, q, 2:], *fv[35, q, :3]], f32(A["pair_solimp"][q]))
+    # lanes past a role's count are zero, and the device enum names as many quads as the host packs
+    assert not rec[0:8, m.nbody:].any() and not rec[30:36, m.npair:].any()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "rsr_mjx_amd", "csrc", "rsr_device.hpp")).read()
+    enum = re.search(r"enum LaneQuad \{(.*?)\};", src, re.S).group(1)
+    names = [t.strip().split("=")[0].strip() for t in enum.replace("\n", " ").split(",") if t.strip()]
+    assert names[-1] == "LQ_COUNT" and len(names) - 1 == LANE_QUADS
