@@ -179,6 +179,7 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 __device__ __forceinline__ float rdlane(float v, int l);
+typedef float v2f __attribute__((ext_vector_type(2)));
 // rows 1,3 += lane 15 of the row below; rows 2,3 += lane 31: lane 63 then holds the wave total
 // Hand-scheduled: the compiler emits every chain on its own with an s_nop between dependent DPP steps (a DPP read
 // needs two wait states after the write) and builds the two row_bcast steps from mov 0 / mov_dpp / add -- 19 issue slots
@@ -584,11 +585,24 @@ __device__ __forceinline__ float chol_factor(float (&a)[C::NV], float (&lt)[C::N
     if (lane == k) dinv = r;
     const float u = a[k];                        // unscaled column k: u_i = H'[i][k]
     a[k] = (lane > k) ? u * r : 0.0f;            // unit-lower column
+    // trailing update a[j] -= L[i][k] * u_j, two columns per instruction where both are coupled to k: the pair of
+    // broadcast values sits in an SGPR pair and the row entries in adjacent VGPRs, so the update is one v_pk_fma_f32
+    auto cpl = [](int j, int kk) { return MASS_ONLY ? C::same_tree(j, kk) : C::coupled(j, kk); };   // structural zeros fold at compile time
+    const v2f akk = {a[k], a[k]};
 #pragma unroll
     for (int j = k + 1; j < C::NV; ++j) {
-      if (!(MASS_ONLY ? C::same_tree(j, k) : C::coupled(j, k))) continue;   // L[j][k] is a structural zero (folds at compile time)
-      float ujk = rdlane(u, j);
-      a[j] -= a[k] * ujk;                        // rows i >= j use it; others hold garbage never read
+      const bool second_of_pair = (j & 1) == 1 && j - 1 > k && cpl(j - 1, k) && cpl(j, k);     // done together with j - 1
+      const bool first_of_pair = (j & 1) == 0 && j + 1 < C::NV && cpl(j, k) && cpl(j + 1, k);
+      if (second_of_pair) continue;
+      if (first_of_pair) {
+        const int j1 = j + 1 < C::NV ? j + 1 : j;
+        v2f aj = {a[j], a[j1]};
+        const v2f uj = {rdlane(u, j), rdlane(u, j1)};
+        aj = __builtin_elementwise_fma(-akk, uj, aj);
+        a[j] = aj.x; a[j1] = aj.y;
+      } else if (cpl(j, k)) {
+        a[j] = __builtin_fmaf(-a[k], rdlane(u, j), a[j]);      // rows i >= j use it; others hold garbage never read
+      }
     }
   }
   // transpose through LDS: T[k][i] = L[i][k]
