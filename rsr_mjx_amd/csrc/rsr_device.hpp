@@ -635,10 +635,13 @@ __device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float
 // broadcast a per-dof vector (lane i holds v_i) and multiply by a register-resident matrix row
 template <class C>
 __device__ __forceinline__ float row_dot(const float (&row)[C::NV], float v) {
-  float acc = 0;
+  // even and odd terms in the two halves of one packed accumulator: NV/2 v_pk_fma_f32 instead of NV v_fma_f32 (without
+  // fast-math the compiler may not split the serial sum itself)
+  static_assert(C::NV % 2 == 0, "paired dot product assumes an even dof count");
+  v2f acc = {0.0f, 0.0f};
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) acc += row[j] * rdlane(v, j);
-  return acc;
+  for (int j = 0; j < C::NV; j += 2) acc = __builtin_elementwise_fma((v2f){row[j], row[j + 1]}, (v2f){rdlane(v, j), rdlane(v, j + 1)}, acc);
+  return acc.x + acc.y;
 }
 
 // =====================================================================================

@@ -29,12 +29,14 @@ __device__ __forceinline__ void jdot(Smem<C>& s, int lane, int nefc, int nbase, 
     float4 q[C::LDJ / 4];
 #pragma unroll
     for (int k = 0; k < C::LDJ / 4; ++k) q[k] = row[k];
-    float acc = 0;
+    v2f acc2 = {0.0f, 0.0f};         // even / odd columns in the halves of a packed accumulator (see row_dot)
 #pragma unroll
-    for (int i = 0; i < C::NV; ++i) {
+    for (int i = 0; i < C::NV; i += 2) {
       const float4& t = q[i / 4];
-      acc += (i % 4 == 0 ? t.x : (i % 4 == 1 ? t.y : (i % 4 == 2 ? t.z : t.w))) * vb[i];
+      const v2f jr = (i % 4 == 0) ? (v2f){t.x, t.y} : (v2f){t.z, t.w};
+      acc2 = __builtin_elementwise_fma(jr, (v2f){vb[i], vb[i + 1]}, acc2);
     }
+    const float acc = acc2.x + acc2.y;
     if (b < nbase) s.bval[b] = acc;
   }
   WSYNC();
