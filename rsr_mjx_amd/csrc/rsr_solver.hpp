@@ -329,9 +329,6 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
   PROF(PS_SOLVE_INIT)
-  float dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
-  float search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
-  PROF(PS_HESS)
   const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
   while (true) {
@@ -343,6 +340,13 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
       done |= scale * gn < m.tolerance;
     } else done = iter >= 1;
     if (uniform_i(done)) break;
+    // Newton direction at the current point.  MJX's loop body ends with _update_gradient (gradient, Hessian, factor,
+    // search), so the reference factors once more after the last iteration and never uses the result; the exit test only
+    // needs cost and gradient, so the Hessian is built here, at the top of an iteration that is known to run: one
+    // assembly + factorisation + solve fewer per solve (of ~4 on the Airbot models, of 2 on Go2), same iterates.
+    const float dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+    const float search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
+    PROF(PS_HESS)
     // ---------------- line search ----------------
     float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
     jdot<C>(s, lane, nefc, nbase, rr, search, jv);
@@ -420,9 +424,6 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
     PROF(PS_UPD)
-    dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
-    search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
-    PROF(PS_HESS)
     ++iter;
   }
   st.niter = iter; st.ls_total = ls_total;
