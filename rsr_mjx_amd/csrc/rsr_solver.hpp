@@ -289,11 +289,23 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
 
 struct SolveStats { int niter, ls_total; };
 
+// Whether integrate() will solve (M + dt*D) qacc = qfrc_smooth + qfrc_constraint (implicitfast, or Euler with damping
+// folded in): the only consumer of qfrc_constraint on the path.  Wave-uniform.
+template <class C>
+__device__ __forceinline__ bool implicit_integration(const DModel& m, const Smem<C>& s, int lane) {
+  bool implicit = m.integrator == INT_IMPLICITFAST;
+  if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
+    float dm = lane < C::NV ? fabsf(s.damp[lane]) : 0.0f;
+    implicit = uniform_i(__ballot(dm != 0.0f) != 0ull);
+  }
+  return implicit;
+}
+
 // Newton solve.  In: Mrow (row i of M in lane i), fs = qfrc_smooth_i, a0 = qacc_smooth_i, warm_i.
 // Out: qacc_i, qfrc_constraint_i.
 template <class C>
 __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
-                      const float (&Mrow)[C::NV], float fs, float a0, float warm, float& qacc_out, float& qfc_out,
+                      const float (&Mrow)[C::NV], float fs, float a0, float warm, bool need_force, float& qacc_out, float& qfc_out,
                       SolveStats& st PROF_ARG) {
   const bool dofl = lane < C::NV;
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
@@ -413,6 +425,9 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
 #pragma unroll
       for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] += alpha * jv[ch];
     }
+    // A single-iteration solve (opt.iterations == 1, Go2) has no exit test to feed, so when nobody reads qfrc_constraint
+    // either (plain Euler) the post-step force / cost / gradient evaluation is dead: stop at the new qacc.
+    if (m.iterations == 1 && !need_force) { ++iter; break; }
     // ---------------- update constraint + gradient ----------------
     rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
     gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
@@ -467,7 +482,8 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   for (int ch = 0; ch < C::NCHUNK; ++ch) rr[ch].aref -= bcoef[ch] * jqv[ch];
   PROF(PS_ROWS)
   out.fsmooth = fs; out.nefc = nefc;
-  solve<C>(m, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, out.qacc, out.qfc, out.st PROF_PASS);
+  const bool need_force = dbg != nullptr || implicit_integration<C>(m, s, lane);
+  solve<C>(m, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, need_force, out.qacc, out.qfc, out.st PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
     if (lane == 0) {
@@ -513,11 +529,7 @@ __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane,
   const int lr = lrec_lane(lane);
   const int4 rj_ids = lrec(m, LQ_J_IDS, lr), rj_ax = lrec(m, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
   float qacc = f.qacc;
-  bool implicit = m.integrator == INT_IMPLICITFAST;
-  if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
-    float dm = lane < C::NV ? fabsf(s.damp[lane]) : 0.0f;
-    implicit = uniform_i(__ballot(dm != 0.0f) != 0ull);
-  }
+  const bool implicit = implicit_integration<C>(m, s, lane);
   if (implicit) {
     float a[C::NV], lt[C::NV];
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
