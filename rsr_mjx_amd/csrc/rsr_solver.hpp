@@ -343,6 +343,10 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   PROF(PS_SOLVE_INIT)
   const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
+  float dinv = 0.0f, hw_fact[C::NCHUNK];
+  bool have_factor = false;
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = 0.0f;
   while (true) {
     bool done;
     if (m.iterations != 1) {
@@ -356,7 +360,18 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     // search), so the reference factors once more after the last iteration and never uses the result; the exit test only
     // needs cost and gradient, so the Hessian is built here, at the top of an iteration that is known to run: one
     // assembly + factorisation + solve fewer per solve (of ~4 on the Airbot models, of 2 on Go2), same iterates.
-    const float dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+    // H = M + J^T diag(hw) J depends on the iterate only through the row weights hw (D on the quadratic piece of a row,
+    // 0 elsewhere): while the active set does not change between iterations -- the usual case close to convergence --
+    // the factorisation of the previous iteration is still the factorisation of H.
+    bool changed = !have_factor;
+#pragma unroll
+    for (int ch = 0; ch < C::NCHUNK; ++ch) changed |= hw[ch] != hw_fact[ch];
+    if (uniform_i(__ballot(changed) != 0ull)) {
+      dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+#pragma unroll
+      for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = hw[ch];
+      have_factor = true;
+    }
     const float search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
     PROF(PS_HESS)
     // ---------------- line search ----------------
