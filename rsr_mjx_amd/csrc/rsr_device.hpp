@@ -723,7 +723,9 @@ __device__ __forceinline__ V3 box_vertex(const float* bm, V3 bp, V3 size, int v)
   return mulv(bm, loc) + bp;
 }
 
-__device__ void plane_box_sat(V3 pp, const float* pm, V3 bp, const float* bm, V3 size, CPts& out, ClipJob& job) {
+// pm / bm: the two frames as values (the caller fetched both matrices in one batch); bm_lds: the box frame in LDS for the
+// clip stage, which runs later and must not keep a register copy alive
+__device__ __forceinline__ void plane_box_sat(V3 pp, const float* pm, V3 bp, const float* bm, const float* bm_lds, V3 size, CPts& out, ClipJob& job) {
   V3 n = col(pm, 2);
   out.n = n; out.cnt = 0; job.kind = 0;
   float smax = -1e30f;
@@ -731,7 +733,7 @@ __device__ void plane_box_sat(V3 pp, const float* pm, V3 bp, const float* bm, V3
   for (int v = 0; v < 8; ++v) smax = fmaxf(smax, dot(pp - box_vertex(bm, bp, size, v), n));
   if (!(smax > 0.0f)) return;
   job.kind = 1; job.o = pp; job.nref = n; job.axu = col(pm, 0); job.axv = col(pm, 1);
-  job.bp = bp; job.size = size; job.bm = bm; job.hu = smax;
+  job.bp = bp; job.size = size; job.bm = bm_lds; job.hu = smax;
 }
 __device__ void plane_box_clip(const ClipJob& job, float* scr, CPts& out) {
   float* sup = scr; float* vx = scr + 8; float* vy = scr + 16;
@@ -754,7 +756,7 @@ __device__ void plane_box_clip(const ClipJob& job, float* scr, CPts& out) {
 }
 
 // 15-axis SAT.  Separated pairs return nothing; edge-edge contacts are finished here; face contacts fill `job`.
-__device__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, CPts& out, ClipJob& job) {
+__device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, CPts& out, ClipJob& job) {
   out.cnt = 0; job.kind = 0;
   const float sa[3] = {sa_.x, sa_.y, sa_.z}, sb[3] = {sb_.x, sb_.y, sb_.z};
   V3 dp = pb - pa;
@@ -997,11 +999,15 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane 
     incl = asf(rp0.w);
     const V3 size1 = v3_xyz(rp1), size2 = v3_xyz(rp2);
     V3 p1 = ld3(&s.x.a.gpos[3 * g1]), p2 = ld3(&s.x.a.gpos[3 * g2]);
-    if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, &s.x.a.gmat[9 * g1], p2, &s.x.a.gmat[9 * g2], size2, pts, job);
+    // both frames up front: inside the SAT the eighteen loads would be issued next to their uses, a few at a time
+    M33 R1, R2;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { R1.m[c] = s.x.a.gmat[9 * g1 + c]; R2.m[c] = s.x.a.gmat[9 * g2 + c]; }
+    if (kind == PAIR_PLANE_BOX) plane_box_sat(p1, R1.m, p2, R2.m, &s.x.a.gmat[9 * g2], size2, pts, job);
     else if (kind == PAIR_BOX_BOX)
-      box_box_sat(p1, &s.x.a.gmat[9 * g1], size1, p2, &s.x.a.gmat[9 * g2], size2, pts, job);
+      box_box_sat(p1, R1.m, size1, p2, R2.m, size2, pts, job);
     else if (kind == PAIR_PLANE_SPHERE) {
-      V3 n = col(&s.x.a.gmat[9 * g1], 2);
+      V3 n = col(R1.m, 2);
       float r = size2.x;
       float dist = dot(p2 - p1, n) - r;
       pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;

@@ -311,32 +311,32 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
   float a[C::NV], lt[C::NV];
   // --- warm start: the cheaper of qacc_warmstart and qacc_smooth (cost only) ---
-  float Ma_w = dofl ? row_dot<C>(Mrow, warm) : 0.0f;
-  jdot<C>(s, lane, nefc, nbase, rr, warm, tmp);
-#pragma unroll
-  for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
-  float cost_w = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw), gs_w = dofl ? (Ma_w - fs) * (warm - a0) : 0.0f, unused = 0.0f;
-  wave_sum3(cost_w, gs_w, unused);
-  cost_w += 0.5f * gs_w;
+  // qacc_smooth is costed first so that the force / weight registers hold the warm-start point afterwards: the warm start
+  // wins almost always, and its context (row cost, Gauss term, force, hw) is then already there instead of being
+  // evaluated a third time.
   float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
   float jar_s[C::NCHUNK];
   jdot<C>(s, lane, nefc, nbase, rr, a0, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
-  float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw);      // (its Gauss term (Ma_s - fs).(a0 - a0) is zero)
+  const float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw);      // (its Gauss term (Ma_s - fs).(a0 - a0) is zero)
+  float Ma_w = dofl ? row_dot<C>(Mrow, warm) : 0.0f;
+  jdot<C>(s, lane, nefc, nbase, rr, warm, tmp);
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
+  float rows_w = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw), gs_w = dofl ? (Ma_w - fs) * (warm - a0) : 0.0f, unused = 0.0f;
+  wave_sum3(rows_w, gs_w, unused);
+  const float cost_w = rows_w + 0.5f * gs_w;
   const bool use_warm = cost_w < cost_s;
   float qacc = use_warm ? warm : a0, Ma = use_warm ? Ma_w : Ma_s;
-  if (!use_warm) {
+  // --- context at the start point ---
+  float gauss = 0.5f * gs_w, rc = rows_w, cost, prev_cost = INFINITY;
+  if (!uniform_i(use_warm)) {
 #pragma unroll
     for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = jar_s[ch];
+    rc = rows_cost<C>(lane, nefc, jaref, rr, force, hw);
+    gauss = 0.0f;
   }
-  // --- context at the start point ---
-  float gauss, cost, prev_cost = INFINITY;
-  float rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
-  gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
-  unused = 0.0f;
-  wave_sum3(rc, gauss, unused);
-  gauss *= 0.5f;
   cost = rc + gauss;
   float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
