@@ -25,7 +25,7 @@ def main():
             orc.step(st, np.clip(rng.normal(size=(n, 5)), -1, 1).astype(np.float32))
         if tshape:
             for k in st:
-                if k in env._views and st[k] is not None and k != "stats":
+                if k in env._views and st[k] is not None and k != "stats" and env.view(k).numel() > 0:     # (skip fields of other env kinds)
                     env.view(k).copy_(torch.from_numpy(st[k].reshape(n, -1)))
         else:
             _push(env, st)
