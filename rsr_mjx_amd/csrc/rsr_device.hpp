@@ -320,6 +320,7 @@ struct Smem {
   // dof of every friction / limit row (their Jacobian row is a single +-1 there) and the Hessian's diagonal accumulator
   int sdof[C::NSP + 1];
   float dgw[C::NV];
+  float jtp[C::NBC * C::NCON > 16 ? 64 : 1];           // J^T f: partial sums of the row groups (lane = group * NV + dof)
   float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
   float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction

@@ -188,16 +188,39 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
     }
   }
   WSYNC();
-  const int col = lane < C::NV ? lane : 0;
-  float acc0 = s.dgw[col], acc1 = 0.0f;
+  if constexpr (C::NBC * C::NCON <= 16) {       // few contact rows (Go2): one group, no exchange
+    const int col = lane < C::NV ? lane : 0;
+    float acc0 = s.dgw[col], acc1 = 0.0f;
 #pragma unroll
-  for (int r = 0; r < C::NEQ; ++r) acc1 += s.x.b.J[r * C::LDJ + col] * rdlane(force[0], r);
-  for (int b = rcon; b < nbase; b += 4) {
-    const int r0 = b, r1 = b + 1 < nbase ? b + 1 : C::NBASE, r2 = b + 2 < nbase ? b + 2 : C::NBASE, r3 = b + 3 < nbase ? b + 3 : C::NBASE;
-    acc0 += s.x.b.J[r0 * C::LDJ + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LDJ + col] * s.bval[r1];
-    acc0 += s.x.b.J[r2 * C::LDJ + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LDJ + col] * s.bval[r3];
+    for (int r = 0; r < C::NEQ; ++r) acc1 += s.x.b.J[r * C::LDJ + col] * rdlane(force[0], r);
+    for (int b = rcon; b < nbase; b += 4) {
+      const int r0 = b, r1 = b + 1 < nbase ? b + 1 : C::NBASE, r2 = b + 2 < nbase ? b + 2 : C::NBASE, r3 = b + 3 < nbase ? b + 3 : C::NBASE;
+      acc0 += s.x.b.J[r0 * C::LDJ + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LDJ + col] * s.bval[r1];
+      acc0 += s.x.b.J[r2 * C::LDJ + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LDJ + col] * s.bval[r3];
+    }
+    return lane < C::NV ? acc0 + acc1 : 0.0f;
   }
-  return lane < C::NV ? acc0 + acc1 : 0.0f;
+  // lane = (row group, dof): the 64 / NV groups walk interleaved quartets of base rows, so the loop is 1 / groups as many
+  // dependent LDS round trips long; the per-group partial sums meet in LDS
+  constexpr int G = 64 / C::NV;
+  const int grp = lane / C::NV, col = lane - grp * C::NV;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  if (grp < G) {
+    for (int b = rcon + 4 * grp; b < nbase; b += 4 * G) {
+      const int r0 = b, r1 = b + 1 < nbase ? b + 1 : C::NBASE, r2 = b + 2 < nbase ? b + 2 : C::NBASE, r3 = b + 3 < nbase ? b + 3 : C::NBASE;
+      acc0 += s.x.b.J[r0 * C::LDJ + col] * s.bval[r0]; acc1 += s.x.b.J[r1 * C::LDJ + col] * s.bval[r1];
+      acc0 += s.x.b.J[r2 * C::LDJ + col] * s.bval[r2]; acc1 += s.x.b.J[r3 * C::LDJ + col] * s.bval[r3];
+    }
+  }
+  s.jtp[lane] = acc0 + acc1;
+  WSYNC();
+  if (lane >= C::NV) return 0.0f;
+  float tot = s.dgw[lane];
+#pragma unroll
+  for (int r = 0; r < C::NEQ; ++r) tot += s.x.b.J[r * C::LDJ + lane] * rdlane(force[0], r);
+#pragma unroll
+  for (int g = 0; g < G; ++g) tot += s.jtp[g * C::NV + lane];
+  return tot;
 }
 
 // H = M + J^T diag(hw) J as 2x2 blocks (lane = block of the lower triangle), then factor.
