@@ -470,6 +470,36 @@ __device__ __forceinline__ void inert_mul(float* o, const float* i, const float*
   o[3] = i[9] * vl.x - u.x; o[4] = i[9] * vl.y - u.y; o[5] = i[9] * vl.z - u.z;
 }
 
+// dst[b][0..NC) = sum of src[k][0..NC) over the bodies k of `mask`, with four lanes per body (lane = 4 b + g): lane g takes
+// the set bits number g, g + 4, g + 8, g + 12 of the mask -- all of its loads in one batch, one LDS round trip for the whole
+// subtree -- and the four partial sums meet with two quad-permute adds.  (One lane per (body, component) item walked the
+// mask four bits per trip: NB * NC / 64 passes of up to four dependent round trips.)  Needs NB <= 16.
+template <class C, int NC>
+__device__ __forceinline__ void subtree_sum_quad(const float* src, float* dst, unsigned mask, int lane) {
+  static_assert(C::NB <= 16, "four lanes per body and sixteen candidate bits per lane quad");
+  const int b = lane >> 2, g = lane & 3;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) if (u < g) mask &= mask - 1u;          // skip the bits of the lanes before this one
+  int k[4]; bool on[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    on[u] = mask != 0u; k[u] = on[u] ? __builtin_ctz(mask) : 0;
+    mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u;      // (0 stays 0)
+  }
+  float v[4][NC];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[u][c] = src[NC * k[u] + c];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float a = (on[0] ? v[0][c] : 0.0f) + (on[1] ? v[1][c] : 0.0f) + (on[2] ? v[2][c] : 0.0f) + (on[3] ? v[3][c] : 0.0f);
+    a += dpp_mov<0xB1>(a);          // quad_perm [1,0,3,2]
+    a += dpp_mov<0x4E>(a);          // quad_perm [2,3,0,1]
+    if (b < C::NB && (c & 3) == g) dst[NC * b + c] = a;
+  }
+}
+
 // =====================================================================================
 // stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
 // =====================================================================================
@@ -479,16 +509,10 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   const int4 rb_misc = lrec(m, LQ_B_MISC, lr), rb_inertia = lrec(m, LQ_B_INERTIA, lr);
   const int4 rd_ids = lrec(m, LQ_D_IDS, lr), rd_masks = lrec(m, LQ_D_MASKS, lr);
   const int max_sub = m.max_sub, max_chain = m.max_chain;
-  // subtree masks of the bodies whose composite inertia items this lane sums below: body b's mask sits in lane b's record,
-  // and a cross-lane read needs its source lane active, so fetch them here, outside the ragged loop
-  constexpr int NPASS_CRB = (C::NB * 10 + 63) / 64;
-  unsigned crb_mask[NPASS_CRB];
-#pragma unroll
-  for (int p = 0; p < NPASS_CRB; ++p) {
-    const int bb = (lane + 64 * p) / 10;
-    const unsigned mb = (unsigned)__shfl(rb_misc.z, bb < C::NB ? bb : 0);     // unconditional: every source lane must be active
-    crb_mask[p] = (bb == 0 || bb >= C::NB) ? 0u : mb;
-  }
+  // subtree mask of body lane / 4 for the four-lanes-per-body composite inertia sum below (body b's mask sits in lane b's
+  // record; a cross-lane read needs its source lane active, so it is fetched here in uniform code)
+  const int qb = lane >> 2;
+  const unsigned crb_mask_q = (unsigned)__shfl(rb_misc.z, qb < C::NB ? qb : 0);
   if (lane < C::NEG) st3(&s.egeom[3 * lane], ld3(&s.x.a.gpos[3 * m.env_ids[C::EG0 + lane]]));
   // subtree centre of mass: lane b sums its subtree
   if (lane < C::NB) {
@@ -530,17 +554,8 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   }
   for (int t = lane; t < C::NV * C::LD; t += 64) s.M[t] = 0.0f;
   WSYNC();
-  // composite inertia: item (b, c) sums cinert over the subtree of b
-#pragma unroll
-  for (int p = 0; p < NPASS_CRB; ++p) {
-    const int t = lane + 64 * p;
-    if (t >= C::NB * 10) continue;
-    int b = t / 10, c = t - 10 * b;
-    unsigned mask = crb_mask[p];
-    float acc = 0;
-    for_bits4_gather(mask, max_sub, [&](int k) { return s.x.a.cinert[10 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
-    s.x.a.crb[t] = acc;
-  }
+  // composite inertia of body b = sum of cinert over its subtree (the world's is not needed: zero)
+  subtree_sum_quad<C, 10>(s.x.a.cinert, s.x.a.crb, (qb == 0 || qb >= C::NB) ? 0u : crb_mask_q, lane);
   WSYNC();
   if (lane < C::NV) {
     int i = lane;
@@ -1073,14 +1088,8 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
   const int4 rd_act = lrec(m, LQ_D_ACT, lr), rd_ctrl = lrec(m, LQ_D_CTRL, lr), rd_bias = lrec(m, LQ_D_BIAS, lr), rd_frc = lrec(m, LQ_D_FRC, lr);
   const int max_sub = m.max_sub, max_chain = m.max_chain;
   const float grav0 = m.gravity[0], grav1 = m.gravity[1], grav2 = m.gravity[2];
-  constexpr int NPASS_FRC = (C::NB * 6 + 63) / 64;
-  unsigned frc_mask[NPASS_FRC];        // subtree masks for the force sums below (see com_crb_mass)
-#pragma unroll
-  for (int p = 0; p < NPASS_FRC; ++p) {
-    const int bb = (lane + 64 * p) / 6;
-    const unsigned mb = (unsigned)__shfl(rb_misc.z, bb < C::NB ? bb : 0);     // unconditional: every source lane must be active
-    frc_mask[p] = bb >= C::NB ? 0u : mb;
-  }
+  const int qb = lane >> 2;            // four lanes per body for the subtree force sums below (see com_crb_mass)
+  const unsigned frc_mask_q = (unsigned)__shfl(rb_misc.z, qb < C::NB ? qb : 0);
   const int site_b = lrec(m, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
   int xfrc_b = 0, xfrc_root = 0; unsigned xfrc_dofs = 0u;
   if constexpr (C::XFRC) {
@@ -1156,16 +1165,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     s.x.a.cfrc[6 * lane + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * lane + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * lane + 5] = f1[5] + tl.z;
   }
   WSYNC();
-#pragma unroll
-  for (int p = 0; p < NPASS_FRC; ++p) {
-    const int t = lane + 64 * p;
-    if (t >= C::NB * 6) continue;
-    int b = t / 6, c = t - 6 * b;
-    unsigned mask = frc_mask[p];
-    float acc = 0;
-    for_bits4_gather(mask, max_sub, [&](int k) { return s.x.a.cfrc[6 * k + c]; }, [&](int, bool on, float v) { acc += on ? v : 0.0f; });
-    s.x.a.cfrcsum[t] = acc;
-  }
+  subtree_sum_quad<C, 6>(s.x.a.cfrc, s.x.a.cfrcsum, qb >= C::NB ? 0u : frc_mask_q, lane);
   WSYNC();
   float smooth = 0.0f;
   if (lane < C::NV) {
