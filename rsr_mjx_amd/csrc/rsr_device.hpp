@@ -500,6 +500,44 @@ __device__ __forceinline__ void subtree_sum_quad(const float* src, float* dst, u
   }
 }
 
+// out[0..6) = sum of vec6[i][0..6) * qvel[i] over the dofs i of `mask`, four lanes per body as in subtree_sum_quad; every
+// lane of the quad receives the sum
+template <class C>
+__device__ __forceinline__ void chain_sum_quad(const Smem<C>& s, const float* vec6, unsigned mask, int lane, int max_bits, float (&out)[6]) {
+  const int g = lane & 3;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) if (u < g) mask &= mask - 1u;
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < max_bits; t += 16) {
+    int k[4]; bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      on[u] = mask != 0u; k[u] = on[u] ? __builtin_ctz(mask) : 0;
+      mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u;
+    }
+    float qd[4], v[4][6];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      qd[u] = s.qvel[k[u]];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[u][c] = vec6[6 * k[u] + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float q = on[u] ? qd[u] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += v[u][c] * q;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float a = acc[c];
+    a += dpp_mov<0xB1>(a);
+    a += dpp_mov<0x4E>(a);
+    out[c] = a;
+  }
+}
+
 // =====================================================================================
 // stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
 // =====================================================================================
@@ -514,16 +552,32 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int la
   const int qb = lane >> 2;
   const unsigned crb_mask_q = (unsigned)__shfl(rb_misc.z, qb < C::NB ? qb : 0);
   if (lane < C::NEG) st3(&s.egeom[3 * lane], ld3(&s.x.a.gpos[3 * m.env_ids[C::EG0 + lane]]));
-  // subtree centre of mass: lane b sums its subtree
-  if (lane < C::NB) {
-    unsigned mask = (unsigned)rb_misc.z;
+  // subtree centre of mass, four lanes per body (see subtree_sum_quad); the world's subtree is every body
+  {
+    unsigned mask = qb < C::NB ? crb_mask_q : 0u;
+    const int g = lane & 3;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (u < g) mask &= mask - 1u;
+    int k[4]; bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      on[u] = mask != 0u; k[u] = on[u] ? __builtin_ctz(mask) : 0;
+      mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u; mask &= mask - 1u;
+    }
+    float mk[4]; V3 pk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { mk[u] = s.mass[k[u]]; pk[u] = ld3(&s.x.a.xipos[3 * k[u]]); }
     float mm = 0; V3 acc = v3(0, 0, 0);
-    struct MP { float m; V3 p; };
-    for_bits4_gather(mask, lane == 0 ? C::NB : max_sub,                     // the world's subtree is every body
-      [&](int k) { MP r; r.m = s.mass[k]; r.p = ld3(&s.x.a.xipos[3 * k]); return r; },
-      [&](int, bool on, const MP& r) { float mk = on ? r.m : 0.0f; mm += mk; acc = acc + r.p * mk; });
-    V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * lane]) : acc * (1.0f / mm);
-    st3(&s.com[3 * lane], c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const float w = on[u] ? mk[u] : 0.0f; mm += w; acc = acc + pk[u] * w; }
+    mm += dpp_mov<0xB1>(mm); mm += dpp_mov<0x4E>(mm);
+    acc.x += dpp_mov<0xB1>(acc.x); acc.x += dpp_mov<0x4E>(acc.x);
+    acc.y += dpp_mov<0xB1>(acc.y); acc.y += dpp_mov<0x4E>(acc.y);
+    acc.z += dpp_mov<0xB1>(acc.z); acc.z += dpp_mov<0x4E>(acc.z);
+    if (g == 0 && qb < C::NB) {
+      V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * qb]) : acc * (1.0f / mm);
+      st3(&s.com[3 * qb], c);
+    }
   }
   WSYNC();
   if (lane < C::NB) {
@@ -1097,20 +1151,16 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     const int src = xfrc_b > 0 && xfrc_b < C::NB ? xfrc_b : 0;
     xfrc_root = __shfl(rb_misc.y, src); xfrc_dofs = (unsigned)__shfl(rb_misc.w, src);
   }
-  // cvel[b] = sum over the dofs on b's chain of cdof*qvel
-  if (lane < C::NB) {
-    unsigned mask = (unsigned)rb_misc.w;
-    float v[6] = {0, 0, 0, 0, 0, 0};
-    for_bits4_gather(mask, max_chain,
-      [&](int i) { Q6 r; r.qd = s.qvel[i];
+  // cvel[b] = sum over the dofs on b's chain of cdof*qvel (four lanes per body)
+  const unsigned dof_mask_raw = (unsigned)__shfl(rb_misc.w, qb < C::NB ? qb : 0);      // unconditional: source lanes must be active
+  const unsigned dof_mask_q = qb < C::NB ? dof_mask_raw : 0u;
+  {
+    float v[6];
+    chain_sum_quad<C>(s, s.cdof, dof_mask_q, lane, max_chain, v);
+    if ((lane & 3) == 0 && qb < C::NB) {
 #pragma unroll
-                   for (int c = 0; c < 6; ++c) r.c[c] = s.cdof[6 * i + c];
-                   return r; },
-      [&](int, bool on, const Q6& r) { float qd = on ? r.qd : 0.0f;
-#pragma unroll
-                   for (int c = 0; c < 6; ++c) v[c] += r.c[c] * qd; });
-#pragma unroll
-    for (int c = 0; c < 6; ++c) s.x.a.cvel[6 * lane + c] = v[c];
+      for (int c = 0; c < 6; ++c) s.x.a.cvel[6 * qb + c] = v[c];
+    }
   }
   // cdof_dot[i] = (velocity of the chain before dof i) x cdof[i]
   if (lane < C::NV) {
@@ -1138,31 +1188,25 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
     V3 off = ld3(&s.spos[3 * lane]) - ld3(&s.com[3 * site_root]);
     st3(&s.sangvel[3 * lane], w); st3(&s.slinvel[3 * lane], v + cross(w, off));
   }
-  // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)
-  if (lane < C::NB) {
-    unsigned mask = (unsigned)rb_misc.w;
-    float a[6] = {0, 0, 0, -grav0, -grav1, -grav2};
-    for_bits4_gather(mask, max_chain,
-      [&](int i) { Q6 r; r.qd = s.qvel[i];
-#pragma unroll
-                   for (int c = 0; c < 6; ++c) r.c[c] = s.x.a.cdofdot[6 * i + c];
-                   return r; },
-      [&](int, bool on, const Q6& r) { float qd = on ? r.qd : 0.0f;
-#pragma unroll
-                   for (int c = 0; c < 6; ++c) a[c] += r.c[c] * qd; });
+  // cacc[b] = [0, -g] + sum over chain dofs of cdof_dot*qvel ; local force = I*cacc + cvel x* (I*cvel)  (chain sum with
+  // four lanes per body; the quad's first lane finishes body b)
+  float aq[6];
+  chain_sum_quad<C>(s, s.x.a.cdofdot, dof_mask_q, lane, max_chain, aq);
+  if ((lane & 3) == 0 && qb < C::NB) {
+    float a[6] = {aq[0], aq[1], aq[2], aq[3] - grav0, aq[4] - grav1, aq[5] - grav2};
     if constexpr (C::XFRC) {
-      if (lane == s.acc_body) {
+      if (qb == s.acc_body) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) s.accb[c] = a[c];
       }
     }
     float f1[6], f2[6];
-    inert_mul(f1, &s.x.a.cinert[10 * lane], a);
-    inert_mul(f2, &s.x.a.cinert[10 * lane], &s.x.a.cvel[6 * lane]);
-    V3 va = ld3(&s.x.a.cvel[6 * lane]), vl = ld3(&s.x.a.cvel[6 * lane + 3]), fa = ld3(f2), fl = ld3(f2 + 3);
+    inert_mul(f1, &s.x.a.cinert[10 * qb], a);
+    inert_mul(f2, &s.x.a.cinert[10 * qb], &s.x.a.cvel[6 * qb]);
+    V3 va = ld3(&s.x.a.cvel[6 * qb]), vl = ld3(&s.x.a.cvel[6 * qb + 3]), fa = ld3(f2), fl = ld3(f2 + 3);
     V3 ta = cross(va, fa) + cross(vl, fl), tl = cross(va, fl);
-    s.x.a.cfrc[6 * lane + 0] = f1[0] + ta.x; s.x.a.cfrc[6 * lane + 1] = f1[1] + ta.y; s.x.a.cfrc[6 * lane + 2] = f1[2] + ta.z;
-    s.x.a.cfrc[6 * lane + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * lane + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * lane + 5] = f1[5] + tl.z;
+    s.x.a.cfrc[6 * qb + 0] = f1[0] + ta.x; s.x.a.cfrc[6 * qb + 1] = f1[1] + ta.y; s.x.a.cfrc[6 * qb + 2] = f1[2] + ta.z;
+    s.x.a.cfrc[6 * qb + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * qb + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * qb + 5] = f1[5] + tl.z;
   }
   WSYNC();
   subtree_sum_quad<C, 6>(s.x.a.cfrc, s.x.a.cfrcsum, qb >= C::NB ? 0u : frc_mask_q, lane);
