@@ -153,6 +153,21 @@ class Oracle:
     def set_ncon_cap(self, cap: int) -> None:
         self.lib.oracle_set_ncon_cap(int(cap))
 
+    def set_ls_rule(self, rule: int, noise_eps: float = 1.0) -> None:
+        """Line-search stop rule: 0 = MJX's (default), 1 = + the HIP kernel's fp32 noise-floor stop, 2 = 1 without the sign test."""
+        self.lib.oracle_set_ls_rule.argtypes = [C.c_int, C.c_double]
+        self.lib.oracle_set_ls_rule(int(rule), float(noise_eps))
+
+    def set_ls_cycle(self, on: bool) -> None:
+        """Exact shortcut of the line search's limit cycles (bit-identical results, fewer iterations)."""
+        self.lib.oracle_set_ls_cycle(int(on))
+
+    def ls_counters(self, reset: bool = False):
+        """(calls, iterations, histogram[52] of iterations per call) of the line search since the last reset."""
+        out = (C.c_longlong * 54)()
+        self.lib.oracle_ls_counters(out, int(reset))
+        return int(out[0]), int(out[1]), np.array(out[2:54], dtype=np.int64)
+
     def max_threads(self) -> int:
         return int(self.lib.oracle_max_threads())
 

@@ -262,6 +262,25 @@ static void odata_free(odata *d) { if (d) { free(d->efc_J); free(d); } }
 /* global knobs (tests flip them) */
 static int g_cull = 1;        /* 1: drop inactive limit rows / separated contacts (result-neutral) */
 static int g_ncon_cap = NCON_MAX;
+/* Line-search stop rule.  0: MJX's (gradient below gtol, no bracket update, or ls_iterations).  1: MJX's plus the HIP kernel's
+ * fp32 noise-floor stop for converging solves (iterations > 1): a bracket end also counts as converged when |derivative| is
+ * below g_ls_noise * eps * (sum |linear terms| + 2 |alpha| sum |quadratic terms|), the rounding noise of the derivative sum.
+ * 2: as 1, and the sign of the derivative is not asked for (|d| below the floor at either end stops the search). */
+/* g_ls_cycle: exact shortcut of the search's limit cycles.  The bracket update can enter a cycle (a Newton step from `lo`
+ * that overshoots is accepted as the new `lo` although its derivative is positive; the roles of the two ends then keep
+ * flipping) that only the iteration cap ends.  The loop state is (lo.alpha, hi.alpha) -- every other field is a function of
+ * alpha -- so once that pair repeats bit for bit with period P the remaining iterations are known: the search runs
+ * (cap - it) mod P more iterations and stops in exactly the state the cap would have left.  Results are bit-identical. */
+static int g_ls_cycle = 0;
+void oracle_set_ls_cycle(int on) { g_ls_cycle = on; }
+static int g_ls_rule = 0;
+static double g_ls_noise = 1.0;
+static long long g_ls_calls = 0, g_ls_iters = 0, g_ls_hist[64];
+void oracle_set_ls_rule(int rule, double noise_eps) { g_ls_rule = rule; g_ls_noise = noise_eps; }
+void oracle_ls_counters(long long *out /* calls, iterations, histogram[52] of iterations per call */, int reset) {
+  if (out) { out[0] = g_ls_calls; out[1] = g_ls_iters; for (int i = 0; i < 52; i++) out[2 + i] = g_ls_hist[i]; }
+  if (reset) { g_ls_calls = 0; g_ls_iters = 0; memset(g_ls_hist, 0, sizeof(g_ls_hist)); }
+}
 void oracle_set_cull(int c) { g_cull = c; }
 void oracle_set_ncon_cap(int c) { g_ncon_cap = c < NCON_MAX ? c : NCON_MAX; }
 
@@ -1236,15 +1255,46 @@ static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad)
   for (int i = 0; i < nv; i++) { sMa += c->search[i] * c->Ma[i]; sf += c->search[i] * d->qfrc_smooth[i]; sMv += c->search[i] * mv[i]; }
   qg[1] = sMa - sf; qg[2] = (real)0.5 * sMv;
 
+  /* rounding-noise scale of the 1-D derivative (rules 1, 2; same sums as rsr_solver.hpp) */
+  real n1 = 0, n2 = 0;
+  if (g_ls_rule != 0 && m->iterations > 1) {
+    for (int r = 0; r < d->nefc; r++) {
+      n1 += (real)fabs((double)(jv[r] * c->Jaref[r] * d->efc_D[r]));
+      if (r >= d->ne && r < d->ne + d->nf && d->efc_floss[r] > 0) n1 += (real)fabs((double)(d->efc_floss[r] * jv[r]));
+      n2 += (real)0.5 * jv[r] * jv[r] * d->efc_D[r];
+    }
+    for (int i = 0; i < nv; i++) n1 += (real)fabs((double)(c->search[i] * c->Ma[i])) + (real)fabs((double)(c->search[i] * d->qfrc_smooth[i]));
+    n2 += (real)fabs((double)qg[2]);
+  }
+  const real noise = (g_ls_rule != 0 && m->iterations > 1) ? (real)(g_ls_noise * 1.1920929e-7) : 0;
+
   lspoint p0 = ls_point(d, c, 0, jv, quad, qg);
   lspoint lo = ls_point(d, c, p0.alpha - p0.deriv0 / p0.deriv1, jv, quad, qg), hi;
   if (lo.deriv0 < p0.deriv0) { hi = p0; } else { hi = lo; lo = p0; }
-  int swap = 1, it = 0;
+  int swap = 1, it = 0, cap = m->ls_iterations;
+  enum { LS_HIST = 8 };
+  real hist_lo[LS_HIST], hist_hi[LS_HIST];
   while (1) {
-    int done = it >= m->ls_iterations;
+    if (g_ls_cycle && cap == m->ls_iterations) {
+      for (int P = 1; P <= LS_HIST && P <= it; P++)
+        if (hist_lo[(it - P) % LS_HIST] == lo.alpha && hist_hi[(it - P) % LS_HIST] == hi.alpha) { cap = it + (m->ls_iterations - it) % P; if (getenv("RSR_LS_TRACE")) fprintf(stderr, "cycle P=%d at it=%d\n", P, it); break; }
+      hist_lo[it % LS_HIST] = lo.alpha; hist_hi[it % LS_HIST] = hi.alpha;
+    }
+    int done = it >= cap;
     done |= !swap;
-    done |= (lo.deriv0 < 0) && (lo.deriv0 > -gtol);
-    done |= (hi.deriv0 > 0) && (hi.deriv0 < gtol);
+    real tol_lo = gtol, tol_hi = gtol;
+    if (noise > 0) {
+      real a = noise * (n1 + 2 * (real)fabs((double)lo.alpha) * n2), b = noise * (n1 + 2 * (real)fabs((double)hi.alpha) * n2);
+      if (a > tol_lo) tol_lo = a;
+      if (b > tol_hi) tol_hi = b;
+    }
+    if (g_ls_rule == 2) {
+      done |= (real)fabs((double)lo.deriv0) < tol_lo;
+      done |= (real)fabs((double)hi.deriv0) < tol_hi;
+    } else {
+      done |= (lo.deriv0 < 0) && (lo.deriv0 > -tol_lo);
+      done |= (hi.deriv0 > 0) && (hi.deriv0 < tol_hi);
+    }
     if (done) break;
     lspoint lo_next = ls_point(d, c, lo.alpha - lo.deriv0 / lo.deriv1, jv, quad, qg);
     lspoint hi_next = ls_point(d, c, hi.alpha - hi.deriv0 / hi.deriv1, jv, quad, qg);
@@ -1261,6 +1311,12 @@ static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad)
     it++;
   }
   d->ls_total += it;
+#pragma omp atomic
+  g_ls_calls++;
+#pragma omp atomic
+  g_ls_iters += it;
+#pragma omp atomic
+  g_ls_hist[it < 51 ? it : 51]++;
   int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
   real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
   if (improved) {

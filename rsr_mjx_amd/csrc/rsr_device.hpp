@@ -251,6 +251,22 @@ __device__ __forceinline__ void for_bits4_gather(unsigned mask, int nbits, L&& l
   }
 }
 
+// wave timeline (diagnostic build): constant-rate clock (100 MHz) at wave start / end, shader cycles of the wave, hardware id
+__device__ __forceinline__ unsigned long long prof_realtime() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ __forceinline__ void prof_timeline(float* d, unsigned long long rt0, unsigned long long ct0) {
+  unsigned long long ct1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct1)::"memory");
+  const unsigned long long rt1 = prof_realtime();
+  unsigned* u = reinterpret_cast<unsigned*>(d);
+  u[0] = (unsigned)rt0; u[1] = (unsigned)(rt0 >> 32); u[2] = (unsigned)rt1; u[3] = (unsigned)(rt1 >> 32);
+  u[4] = (unsigned)(ct1 - ct0);
+  u[5] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+  u[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+}
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
@@ -263,10 +279,15 @@ __device__ __forceinline__ unsigned long long prof_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
-#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < PS_COUNT; ++i_) prof_.acc[i_] = 0; prof_.t0 = prof_now();
+#define PROF_DECL Prof prof_; for (int i_ = 0; i_ < PS_COUNT; ++i_) prof_.acc[i_] = 0; const unsigned long long prof_rt0_ = prof_realtime(); prof_.t0 = prof_now(); const unsigned long long prof_ct0_ = prof_.t0;
 #define PROF_ARG , Prof& prof_
 #define PROF_PASS , prof_
 #define PROF(stage) { unsigned long long t_ = prof_now(); prof_.acc[stage] += t_ - prof_.t0; prof_.t0 = t_; }
+#elif defined(RSR_TIMELINE)      // start / end stamps only: the wave timeline without the per-stage stamps' overhead
+#define PROF_DECL const unsigned long long prof_rt0_ = prof_realtime(); unsigned long long prof_ct0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_ct0_)::"memory");
+#define PROF_ARG
+#define PROF_PASS
+#define PROF(stage)
 #else
 #define PROF_DECL
 #define PROF_ARG

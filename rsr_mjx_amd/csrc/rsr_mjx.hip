@@ -407,7 +407,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   float Mrow[C::NV];
   FwdOut<C> f;
   for (int fr = 0; fr < m.n_frames; ++fr) {
-#ifdef RSR_PROFILE
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
 #else
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
@@ -532,6 +532,9 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float* d = a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7200;
     for (int i = 0; i < PS_COUNT; ++i) d[i] = (float)prof_.acc[i];
   }
+#endif
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
+  if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300, prof_rt0_, prof_ct0_);
 #endif
 }
 
@@ -725,7 +728,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   float Mrow[C::NV];
   FwdOut<C> f;
   for (int fr = 0; fr < m.n_frames; ++fr) {
-#ifdef RSR_PROFILE
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
 #else
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
@@ -929,6 +932,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float* d = a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7200;
     for (int i = 0; i < PS_COUNT; ++i) d[i] = (float)prof_.acc[i];
   }
+#endif
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
+  if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300, prof_rt0_, prof_ct0_);
 #endif
 }
 

@@ -431,13 +431,41 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     LSPoint lo = ls_point<C>(nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), lw, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
     bool swap = true; int it = 0;
+    // Limit cycles of the bracket update, cut short exactly.  A Newton step from `lo` that overshoots is accepted as the new
+    // `lo` although its derivative is positive; the two ends then keep trading roles and only the iteration cap ends the
+    // search (4-15 % of the searches on the Airbot models, 50 iterations each: they were the long tail of the wave
+    // lifetimes).  The loop state is the pair (lo.alpha, hi.alpha) -- every other field is a function of alpha -- so once
+    // the pair repeats bit for bit with period P the rest is known: (cap - it) mod P more iterations leave exactly the state
+    // the cap would have left.  Results are bit-identical to running the cap out (the oracle has the same switch).
+    int cap = m.ls_iterations;
+    constexpr int LS_HIST = 8;
+    int hist_lo[LS_HIST], hist_hi[LS_HIST];
+#pragma unroll
+    for (int k = 0; k < LS_HIST; ++k) { hist_lo[k] = 0; hist_hi[k] = 0; }
+    const bool cut_cycles = m.iterations > 1;
     while (true) {
-      bool ldone = it >= m.ls_iterations;
+      if (cut_cycles && cap == m.ls_iterations) {
+        const int la = uniform_i(__float_as_int(lo.alpha)), ha = uniform_i(__float_as_int(hi.alpha));
+        bool found = false;
+#pragma unroll
+        for (int P = 1; P <= LS_HIST; ++P) {      // smallest period first; hist[P - 1] = the pair P iterations ago
+          if (!found && P <= it && hist_lo[P - 1] == la && hist_hi[P - 1] == ha) { found = true; cap = it + (m.ls_iterations - it) % P; }
+        }
+#pragma unroll
+        for (int k = LS_HIST - 1; k > 0; --k) { hist_lo[k] = hist_lo[k - 1]; hist_hi[k] = hist_hi[k - 1]; }
+        hist_lo[0] = la; hist_hi[0] = ha;
+      }
+      bool ldone = it >= cap;
       ldone |= !swap;
       float tol_lo = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(lo.alpha) * n2));
       float tol_hi = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(hi.alpha) * n2));
-      ldone |= (lo.d0 < 0.0f) && (lo.d0 > -tol_lo);
-      ldone |= (hi.d0 > 0.0f) && (hi.d0 < tol_hi);
+      if (NOISE > 0.0f) {     // below the rounding noise of its own sum the derivative has no sign
+        ldone |= fabsf(lo.d0) < tol_lo;
+        ldone |= fabsf(hi.d0) < tol_hi;
+      } else {
+        ldone |= (lo.d0 < 0.0f) && (lo.d0 > -tol_lo);
+        ldone |= (hi.d0 > 0.0f) && (hi.d0 < tol_hi);
+      }
       if (uniform_i(ldone)) break;
       float al3[3] = {lo.alpha - lo.d0 * __builtin_amdgcn_rcpf(lo.d1), hi.alpha - hi.d0 * __builtin_amdgcn_rcpf(hi.d1), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
