@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the fused Airbot-cube env step (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU, before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -30,24 +30,68 @@ BYTES_PER_ENV_STEP = 728           # ... without DR
 VALU_PEAK_WAVE_INST_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md constants)
 
 
-def pmc_profile(workload: str, n: int, dr_on: bool):
-    """HBM traffic and instruction counts per launch from the committed rocprofv3 PMC passes (profiles/round1_final_pmc_*.csv,
+PROFILE_ROUND = "round2"
+
+
+def csrc_sha16() -> str:
+    """SHA-256 (first 16 hex digits) of the kernel sources the running library was built from: rsr_mjx_amd/csrc/*.hip, *.hpp and
+    include/rsr_mjx.h, in name order.  tools/rocpd_summary.py stores the same hash in every PMC summary it writes."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "rsr_mjx_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.join(ROOT, "include", "rsr_mjx.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(workload: str, n: int, dr_on: bool, sha: str):
+    """HBM traffic and instruction counts per launch from the committed rocprofv3 PMC passes (profiles/round2_pmc_*_<workload>.csv,
     collected by tools/gpu_final_profile.sh on this very command line).  PMC cannot be read from inside the process, so the
-    numbers apply only to the configuration they were measured on (headline cube, 8192 envs, DR on); otherwise None."""
-    if workload != "cube" or n != 8192 or not dr_on:
-        return None
+    numbers are quoted only when they were measured on this configuration (8192 envs, default DR) AND on this build: every
+    summary carries the hash of the kernel sources it was collected on; on a mismatch the fields are null."""
+    if n != 8192 or (workload == "cube" and not dr_on):
+        return None, "PMC summaries exist for the default configuration only"
     import csv
     vals = {}
     for tag in ("fetch", "write", "inst"):
-        path = os.path.join(ROOT, "profiles", f"round1_final_pmc_{tag}.csv")
+        path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{tag}_{workload}.csv")
         if not os.path.exists(path):
-            return None
+            return None, f"no committed PMC summary {os.path.basename(path)}"
         for row in csv.DictReader(open(path)):
             if "step_kernel" in row["kernel"]:
+                if row.get("csrc_sha16") != sha:
+                    return None, (f"{os.path.basename(path)} was collected on kernel sources {row.get('csrc_sha16')}, this build is {sha}: "
+                                  "counters not quoted")
                 vals[row["counter"]] = float(row["avg_per_dispatch"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return vals
+        return None, "PMC summaries lack FETCH_SIZE / WRITE_SIZE"
+    return vals, f"profiles/{PROFILE_ROUND}_pmc_{{fetch,write,inst}}_{workload}.csv, collected on kernel sources {sha}"
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start N ranks of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (the reference finds its devices itself, RSR/train.py:170-180).  Runs before
+    anything touches the GPU in this process; the children are fresh interpreters.  Rank 0's stdout is ours."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   RSR_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def cpu_baseline(blob: bytes, dr, seconds: float = 12.0, nu: int = 5, act_std: float = 1.0):
@@ -108,6 +152,36 @@ def sub_batched_rate(envdef, keys, dr, n, ep_len, actions, parts, steps, warmup)
             "note": f"{parts} x {m} envs on {parts} HIP streams, {steps} steps each, no lock-step between sub-batches; this GPU only"}
 
 
+def dry_run(args, rank: int, world: int) -> None:
+    """The N > 1 plumbing without a GPU: gloo rendezvous, barrier, MAX-over-ranks time, the metric all_gather, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from rsr_mjx_amd.distributed import gather_metrics, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n = args.envs
+    lo, hi = shard_range(n * world, rank, world)
+    metrics = torch.tensor([float(args.steps * n), float(lo), float(hi), float(rank)])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                  # ranks finish at different times: the reported time is the slowest rank's
+    allm = gather_metrics(metrics)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": float(allm[:, 0].sum()) / float(t.item()), "unit": "env-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / args.steps * 1e3,
+                          "scaling": "weak", "shards": [[int(a), int(b)] for a, b in allm[:, 1:3].tolist()],
+                          "ranks_seen": [int(r) for r in allm[:, 3].tolist()]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,19 +196,30 @@ def main():
     ap.add_argument("--sub-batches", type=int, default=2,
                     help="also report the rate with the same envs stepped as this many independent sub-batches on their own HIP "
                          "streams (0 = skip); `value` is always the lock-step figure")
+    ap.add_argument("--replicated-dr", action="store_true",
+                    help="every GPU draws the same domain-randomisation key set, as the reference does (RSR/train.py:212-217); "
+                         "default: one global key fan-out sliced per rank, so env i is the same env for any GPU count")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: ranks rendezvous over gloo and run the launcher, the barrier / MAX-over-ranks timing and the "
+                         "end-of-rollout gather on synthetic per-rank metrics (CPU test of the N > 1 plumbing)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     from rsr_mjx_amd import prng
-    from rsr_mjx_amd.distributed import gather_metrics, shard_keys, shard_range
-    from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
+    from rsr_mjx_amd.distributed import gather_metrics, randomization_keys, shard_keys, shard_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    from rsr_mjx_amd.envs.airbot import AirbotPlayBase, domain_randomize
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -160,7 +245,7 @@ def main():
         args.no_dr = True
     else:
         envdef = AirbotPlayBase(device=f"cuda:{local_rank}")
-        dr = None if args.no_dr else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), total)[lo:hi])
+        dr = None if args.no_dr else domain_randomize(envdef.sys, randomization_keys(prng.PRNGKey(1), total, rank, world, args.replicated_dr))
         ep_len, act_std, wl_name = 1200, 1.0, "AirbotPlayBase cube_env"
     env = envdef.batched(n, episode_length=ep_len, auto_reset=True, randomization=dr)   # train.py:47-50
     state = env.reset(keys)
@@ -208,7 +293,8 @@ def main():
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()
-        pmc = pmc_profile(args.workload, n, not args.no_dr)
+        sha = csrc_sha16()
+        pmc, pmc_note = pmc_profile(args.workload, n, not args.no_dr, sha)
         traffic = None if pmc is None else (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0      # rocprofv3 reports KiB
         out = {
             "metric": "env-steps/sec at num_envs=8192, Airbot cube" if args.workload == "cube" else f"env-steps/sec, {wl_name}",
@@ -228,6 +314,7 @@ def main():
                             f"auto-reset, domain randomisation {'off' if args.no_dr else 'on'}, {env.dims.n_frames} substeps/env-step, "
                             f"actions N(0,{act_std}) clipped to +-1",
                 "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
+                "csrc_sha16": sha, "dr_keys": "replicated per GPU (RSR/train.py:212-217)" if args.replicated_dr else "global fan-out sliced per rank",
                 "kernel": {"cube": "rsr::step_kernel<CubeDims, ENV_CUBE>", "tshape": "rsr::step_kernel<TShapeDims, ENV_TSHAPE>",
                            "go2": "rsr::go2_step_kernel<Go2Dims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>"}[args.workload] + " (one wavefront per env)",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
@@ -240,9 +327,9 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per * n, "avg_launch_ms": avg_launch_s * 1e3,
                 "traffic_detail": None if pmc is None else {
                     "fetch_bytes": pmc["FETCH_SIZE"] * 1024.0, "write_bytes": pmc["WRITE_SIZE"] * 1024.0,
-                    "source": "profiles/round1_final_pmc_fetch.csv, _write.csv (separate rocprofv3 --pmc passes, per launch; "
-                              "dword-per-lane accesses are uncalibrated on gfx950, MI355X_MICROARCH.md HBM section); writes above "
-                              "the record size are register spills to scratch memory (DESIGN.md 4)"},
+                    "source": "separate rocprofv3 --pmc passes, per launch; dword-per-lane accesses are uncalibrated on gfx950 "
+                              "(MI355X_MICROARCH.md HBM section); writes above the record size are register spills to scratch memory"},
+                "pmc_source": pmc_note,
                 "valu": None if pmc is None or "SQ_INSTS_VALU" not in pmc else {
                     "wave_instructions_per_env_step": pmc["SQ_INSTS_VALU"] / n,
                     "achieved_wave_inst_per_s": pmc["SQ_INSTS_VALU"] / avg_launch_s,

@@ -24,6 +24,16 @@ def shard_keys(key_env: np.ndarray, total: int, rank: int, world: int) -> np.nda
     return prng.split(key_env, total)[lo:hi]
 
 
+def randomization_keys(key: np.ndarray, total: int, rank: int, world: int, replicated: bool = False) -> np.ndarray:
+    """Keys of this rank's domain-randomisation draws.  Default: split(key, total) sliced like the env keys (env i is the same
+    env for any GPU count).  replicated: every rank draws split(key, total / world) -- the reference hands every device the
+    same randomisation rng (RSR/train.py:212-217: `randomization_rng = split(key_env, num_envs // local_device_count)`)."""
+    lo, hi = shard_range(total, rank, world)
+    if replicated:
+        return prng.split(key, hi - lo)
+    return prng.split(key, total)[lo:hi]
+
+
 def gather_metrics(vec):
     """all_gather of a 1-D float tensor -> [world, k] (identity for a single process)."""
     import torch

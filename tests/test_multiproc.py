@@ -65,3 +65,36 @@ def test_two_rank_sharding_matches_single_process(cube_model, oracle_mod, tmp_pa
     assert shard_range(total, 1, world) == (8, 16)
     with pytest.raises(ValueError):
         shard_range(15, 0, 2)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (one per GPU on a GPU box; here the
+    --dry-run leg: gloo rendezvous, barrier + MAX-over-ranks timing, the metric all_gather) and prints rank 0's one JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "7", "--envs", "48"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["shards"] == [[0, 48], [48, 96]] and line["ranks_seen"] == [0, 1]
+    assert line["ms_per_step"] * 7 >= 20.0 - 1e-6          # the slower rank (sleeps 20 ms) sets the time
+    # --gpus N with a WORLD_SIZE that disagrees is refused rather than silently run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)
+
+
+def test_randomization_keys_sliced_or_replicated():
+    """Default: one global key fan-out sliced per rank; replicated: every rank draws the same set (RSR/train.py:212-217)."""
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.distributed import randomization_keys
+    key = prng.PRNGKey(5)
+    full = prng.split(key, 8)
+    a, b = randomization_keys(key, 8, 0, 2), randomization_keys(key, 8, 1, 2)
+    np.testing.assert_array_equal(np.concatenate([a, b]), full)
+    ra, rb = randomization_keys(key, 8, 0, 2, replicated=True), randomization_keys(key, 8, 1, 2, replicated=True)
+    np.testing.assert_array_equal(ra, rb)
+    np.testing.assert_array_equal(ra, prng.split(key, 4))

@@ -1,22 +1,30 @@
 #!/bin/bash
-# Round-end measurement on the GPU box: kernel-trace stats of the default bench, then PMC passes (each in its own run,
-# with --kernel-trace only, as the pool requires).  Outputs under gpurun_out/final/.
+# Round-end evidence on the GPU box for ALL FOUR workloads: rocprofv3 kernel-trace stats of a bench run, then the PMC passes
+# (each in its own run with --kernel-trace only, as the pool requires), summarised into profiles/round2_*_<workload>.csv with
+# the hash of the kernel sources (tools/rocpd_summary.py), then the plain bench lines.  usage: tools/gpu_final_profile.sh [workloads...]
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
-mkdir -p $O
+P=$R/gpurun_out/final/profiles
+mkdir -p $O $P
+WL=${@:-cube tshape go2 go2rough}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python3 $R/bench.py --steps 300 --warmup 50 --sub-batches 0 > $O/bench_cube_profiled.json 2> $O/bench_cube_profiled.err
-echo "trace done"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $O/pmc_inst -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_inst.json 2> $O/pmc_inst.err
-echo "pmc inst done"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS -d $O/pmc_cyc -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_cyc.json 2> $O/pmc_cyc.err
-echo "pmc cycles done"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-echo "pmc fetch done"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pmc -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_write.json 2> $O/pmc_write.err
-echo "pmc write done"
+db() { find $1 -name "*.db" | head -1; }
+for w in $WL; do
+  rm -rf $O/trace_$w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace_$w -o bench -- python3 $R/bench.py --workload $w --steps 300 --warmup 50 --sub-batches 0 --no-cpu-baseline > $P/round2_bench_${w}_under_rocprofv3.json 2> $O/trace_$w.err
+  python3 $R/tools/rocpd_summary.py kernels $(db $O/trace_$w) $P/round2_kernel_stats_$w.csv
+  echo "$w trace done"
+  for pass in "inst SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
+              "cyc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \
+              "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+    set -- $pass; tag=$1; shift
+    rm -rf $O/pmc_${tag}_$w
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${tag}_$w -o pmc -- python3 $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_${tag}_$w.json 2> $O/pmc_${tag}_$w.err
+    python3 $R/tools/rocpd_summary.py pmc $(db $O/pmc_${tag}_$w) $P/round2_pmc_${tag}_$w.csv
+  done
+  echo "$w pmc done"
+done
 cd $R
-for w in cube tshape go2 go2rough; do timeout -k 10 200 python3 bench.py --workload $w --steps 300 --warmup 50 > $O/bench_$w.json 2> $O/bench_$w.err; done
-echo "other workloads done"
-ls -R $O | head -50
+for w in $WL; do timeout -k 10 200 python3 bench.py --workload $w --steps 300 --warmup 50 > $P/round2_bench_$w.json 2> $O/bench_$w.err; echo "$w bench done"; done
+ls $P
