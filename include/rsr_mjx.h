@@ -110,6 +110,12 @@ int rsr_step(rsr_batch* b, const float* action, void* hip_stream);
  * (strides in elements of 4 bytes); shape[0] = num_envs, shape[1] = field width. */
 int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shape[2], int64_t stride[2]);
 
+/* Scheduling knob of rsr_step, results are bit-identical for every value: the launch runs persistent waves that draw
+ * (env, phase) work units from a queue, an env-step being cut into `units` groups of consecutive physics substeps
+ * (1 <= units <= n_frames; larger values are clamped).  Shorter units shorten the drain at the end of a launch.  No
+ * counterpart in the reference (XLA schedules its own kernels).  The Go2 kernels ignore it for now. */
+int rsr_batch_set_schedule(rsr_batch* b, int units);
+
 /* Optional per-stage dump for parity debugging: device float buffer [num_envs, RSR_DEBUG_FLOATS]
  * filled by the next rsr_step/rsr_reset from the LAST physics forward pass (NULL disables). */
 #define RSR_DEBUG_FLOATS 8192

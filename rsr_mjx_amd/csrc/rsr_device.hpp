@@ -81,6 +81,24 @@ struct Layout {
   int persist_end;    // [0, persist_end) = pipeline state restored by auto-reset (qpos..site_xpos)
 };
 
+// Work-queue dispatch of a step launch (persistent waves).  An env-step is cut into `units` consecutive groups of physics
+// substeps; a wave draws tickets t = phase * n + env from one counter and runs unit `phase` of `env`, handing the pipeline
+// state (qpos, qvel, ctrl, qacc_warmstart, time) to the next phase through the env's record.  Tickets are drawn in
+// dependency order, so the wave that holds (env, phase - 1) drew its ticket earlier and is running: waits always end.
+// Why: with one launch-long unit per env the last waves of a launch run at their full lifetime while most SIMDs are
+// already idle (8192 envs = 4 rounds of 2048 slots: ~20 % of the launch); shorter units shorten that drain.
+struct Sched {
+  int* ticket;          // [2]: counter of launch `launch_id & 1`; the wave that draws ticket 0 zeroes the other one
+  unsigned* flags;      // [n]: launch_id * units + (phases of the env completed in this launch)
+  unsigned launch_id;   // 1, 2, ... per rsr_step of the batch
+  int units;            // phases per env-step (1 = the whole step in one unit)
+};
+
+// relaxed agent-scope accesses = global_load / global_store ... sc1: served by / written through to memory, past the CU's L1
+// and the XCD's L2, which are not coherent across CUs / XCDs within a launch (MI355X_MICROARCH.md, inter-workgroup visibility)
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct StepArgs {
   float* state;                 // [N][rec]
   const float* action;          // [N][nu]         (step)

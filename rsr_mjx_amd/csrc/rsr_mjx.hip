@@ -15,7 +15,10 @@
 namespace rsr {
 
 // Airbot cube: nq 22, nv 20, nu 5, nbody 14, njnt 10, ngeom 23, nsite 1, npair 45, neq 1, nf 8, nl 8
-using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ 24, /*OBS*/ 23, /*NMET*/ 3, 0, 0, 4, 0,
+#ifndef RSR_CUBE_NCON
+#define RSR_CUBE_NCON 24
+#endif
+using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_NCON, /*OBS*/ 23, /*NMET*/ 3, 0, 0, 4, 0,
                       /*ISO: the target body's free joint, dofs 8..13*/ 8, 14>;
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
@@ -344,23 +347,53 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
 #ifndef RSR_WAVES_PER_EU
 #define RSR_WAVES_PER_EU 2
 #endif
+#ifndef RSR_PERSISTENT
+#define RSR_PERSISTENT 1             // 1: a wave loops over tickets; 0: one ticket per workgroup, grid = units * n (measured: DESIGN.md 4)
+#endif
+#ifndef RSR_DEFAULT_UNITS
+#define RSR_DEFAULT_UNITS 2          // phases per env-step of the work-queue dispatch (measured: DESIGN.md 4)
+#endif
 template <class C, int ENV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
-void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) {
   const DModel& m = *mp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= a.n) return;
-  float* rec = a.state + (size_t)e * L.rec;
+  const int lane = threadIdx.x;
   const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
   constexpr int JQ = ENV == ENV_TSHAPE ? (int)TID_JOINTQ : (int)ID_JOINTQ;
+  const int units = sc.units, total = units * a.n;
+  int* const ticket = sc.ticket + (sc.launch_id & 1u);
+  for (;;) {                                                   // persistent wave: one work unit (env, phase) per trip
+  int tk = 0;
+  if (lane == 0) {
+    tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == 0) __hip_atomic_store(sc.ticket + ((sc.launch_id + 1u) & 1u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's counter
+  }
+  tk = uniform_i(tk);
+  if (tk >= total) break;                                      // every wave reaches this: the queue only drains
+  const int phase = tk / a.n, e = tk - phase * a.n;
+  const bool first = phase == 0, last = phase == units - 1;
+  float* rec = a.state + (size_t)e * L.rec;
   PROF_DECL
   // ---- load the record ----
-  for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
-  float warm = 0.0f;
-  if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
-  float time = rec[L.time];
+  float warm = 0.0f, time;
+  if (first) {
+    for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
+    if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
+    time = rec[L.time];
+  } else {
+    // the previous phase of this env (another wave, any CU) has published its state: poll its flag, then read every handed-off
+    // word past the caches.  The spin is bounded; a timeout is reported through stats[3] = -1 and the unit runs on stale data.
+    const unsigned want = sc.launch_id * (unsigned)units + (unsigned)phase;
+    int spins = 0;
+    while (__hip_atomic_load(sc.flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); ++spins; }
+    if (spins >= (1 << 22) && lane == 0) reinterpret_cast<int*>(rec + L.stats)[3] = -1;
+    for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = ld_sc1(&rec[L.qpos + t]);
+    if (lane < C::NV) { s.qvel[lane] = ld_sc1(&rec[L.qvel + lane]); warm = ld_sc1(&rec[L.warm + lane]); }
+    if (lane < C::NU) s.ctrl[lane] = ld_sc1(&rec[L.ctrl + lane]);
+    time = ld_sc1(&rec[L.time]);
+  }
   load_overrides<C>(m, s, a, e, lane);
   const float done_prev = rec[L.done];
   float steps = rec[L.steps];
@@ -373,7 +406,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     aux_old[0] = rec[L.new_cube_pos]; aux_old[1] = rec[L.new_cube_pos + 1];
   }
   // ---- prologue: ctrl shaping; uses the stale xpos / site_xpos of the previous forward pass ----
-  if (lane < C::NU) {
+  if (first && lane < C::NU) {
 #pragma clang fp contract(off)   // env algebra is evaluated op by op, as the reference's JAX-CPU path does
     float delta = m.env_action_scale[lane] * a.action[(size_t)e * C::NU + lane];
     float act = rec[L.ctrl + lane] + delta;
@@ -406,15 +439,33 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   // ---- n_frames x mjx.step ----
   float Mrow[C::NV];
   FwdOut<C> f;
-  for (int fr = 0; fr < m.n_frames; ++fr) {
+  for (int fr = phase * m.n_frames / units; fr < (phase + 1) * m.n_frames / units; ++fr) {
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
 #else
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
 #endif
-    forward<C>(m, s, lane, Mrow, warm, f, dbg PROF_PASS);
-    integrate<C>(m, s, lane, Mrow, f PROF_PASS);
+    // the lane index passes through an opaque zero per substep: values derived from it (masks, LDS addresses) are then
+    // recomputed in each substep instead of being hoisted out of the loop, kept live across the solver and spilled
+    const int lane_s = lrec_lane(lane);
+    forward<C>(m, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, s, lane_s, Mrow, f PROF_PASS);
     time += m.timestep;
+  }
+  if (!last) {
+    // hand the pipeline state to the next phase: write-through stores, drained, then the flag (one wave = one workgroup)
+    for (int t = lane; t < C::NQ; t += 64) st_sc1(&rec[L.qpos + t], s.qpos[t]);
+    if (lane < C::NV) { st_sc1(&rec[L.qvel + lane], s.qvel[lane]); st_sc1(&rec[L.warm + lane], warm); }
+    if (lane < C::NU) st_sc1(&rec[L.ctrl + lane], s.ctrl[lane]);
+    if (lane == 0) st_sc1(&rec[L.time], time);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(sc.flags + e, sc.launch_id * (unsigned)units + (unsigned)phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
+    if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300 + 8 * phase, prof_rt0_, prof_ct0_);
+#endif
+    if (!RSR_PERSISTENT) break;
+    WSYNC();
+    continue;
   }
   // ---- epilogue: reward, done, obs, info; derived data are from the last forward pass ----
   float done = 0.0f;
@@ -534,8 +585,11 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
 #endif
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
-  if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300, prof_rt0_, prof_ct0_);
+  if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300 + 8 * phase, prof_rt0_, prof_ct0_);
 #endif
+  if (!RSR_PERSISTENT) break;
+  WSYNC();                                                     // the next unit reuses this wave's LDS image
+  }
 }
 
 // ---------------------------------------------------------------- Go2 reset kernel (joystick.py:123-203 + wrappers)
@@ -733,8 +787,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 #else
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
 #endif
-    forward<C>(m, s, lane, Mrow, warm, f, dbg PROF_PASS);
-    integrate<C>(m, s, lane, Mrow, f PROF_PASS);
+    const int lane_s = lrec_lane(lane);        // see step_kernel
+    forward<C>(m, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, s, lane_s, Mrow, f PROF_PASS);
     time += m.timestep;
   }
   // ---- sensors of the last forward pass, IMU FIFOs (:220-235) ----
@@ -997,6 +1052,10 @@ struct rsr_batch {
   const float* dr_ex[5];    // body_ipos, qpos0, dof_armature, actuator_gainprm, actuator_biasprm
   float* debug;
   hipEvent_t ev0, ev1; bool timing; int launches;
+  // work-queue dispatch of the Airbot step kernels (rsr_device.hpp: Sched)
+  int* sched;           // device: ticket[2], then flags[n]
+  unsigned launch_id;
+  int units, step_grid;
 };
 
 static Layout make_layout(const rsr_dims& d) {
@@ -1181,6 +1240,23 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   HIPCHK(hipMemcpy(b->dblob, m->blob.data(), m->blob.size(), hipMemcpyHostToDevice));
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return rc; }
+  b->sched = nullptr; b->launch_id = 0; b->units = 1; b->step_grid = 0;
+  if (m->dims.env_kind != rsr::ENV_GO2) {
+    const size_t sb = (2 + (size_t)num_envs) * sizeof(int);
+    if (hipMalloc(&b->sched, sb) != hipSuccess) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
+    (void)hipMemset(b->sched, 0, sb);
+    // resident waves of the step kernel on this device: the grid of the persistent launch
+    int per_cu = 0; hipDeviceProp_t prop;
+    hipError_t oe = m->dims.env_kind == rsr::ENV_TSHAPE
+      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>, 64, sizeof(rsr::Smem<rsr::TShapeDims>))
+      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>, 64, sizeof(rsr::Smem<rsr::CubeDims>));
+    if (oe != hipSuccess || hipGetDeviceProperties(&prop, hip_device) != hipSuccess || per_cu <= 0) { per_cu = 8; prop.multiProcessorCount = 256; }
+    b->step_grid = per_cu * prop.multiProcessorCount;
+    const char* ev = std::getenv("RSR_UNITS");
+    b->units = ev ? std::atoi(ev) : RSR_DEFAULT_UNITS;
+    if (b->units < 1) b->units = 1;
+    if (b->units > m->dims.n_frames) b->units = m->dims.n_frames;
+  }
   b->dmodel = nullptr;
   if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
   HIPCHK(hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice));
@@ -1195,6 +1271,7 @@ extern "C" void rsr_batch_destroy(rsr_batch* b) {
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->dblob) (void)hipFree(b->dblob);
   if (b->dmodel) (void)hipFree(b->dmodel);
+  if (b->sched) (void)hipFree(b->sched);
   if (b->owns_state && b->state) (void)hipFree(b->state);
   delete b;
 }
@@ -1220,6 +1297,12 @@ extern "C" int rsr_batch_set_dr_field(rsr_batch* b, int dr_field, const float* d
       return RSR_OK;
     default: return fail(RSR_ERR_ARG, "rsr_batch_set_dr_field: unknown field");
   }
+}
+
+extern "C" int rsr_batch_set_schedule(rsr_batch* b, int units) {
+  if (!b || units < 1) return fail(RSR_ERR_ARG, "rsr_batch_set_schedule: bad argument");
+  b->units = units > b->model->dims.n_frames ? b->model->dims.n_frames : units;
+  return RSR_OK;
 }
 
 extern "C" int rsr_batch_set_debug(rsr_batch* b, float* dev_buffer) {
@@ -1263,12 +1346,17 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
     rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a);
-  else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
-    hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
-                       b->dmodel, b->model->layout, a);
-  else
-    hipLaunchKernelGGL((rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
-                       b->dmodel, b->model->layout, a);
+  else {
+    rsr::Sched sc{b->sched, reinterpret_cast<unsigned*>(b->sched + 2), ++b->launch_id, b->units};
+    const long long work = (long long)b->units * b->n;
+    const int grid = (int)(RSR_PERSISTENT && work > b->step_grid ? b->step_grid : work);
+    if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
+      hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
+                         b->dmodel, b->model->layout, a, sc);
+    else
+      hipLaunchKernelGGL((rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
+                         b->dmodel, b->model->layout, a, sc);
+  }
   HIPCHK(hipGetLastError());
   if (b->timing) b->launches++;
   return RSR_OK;

@@ -231,6 +231,10 @@ class BatchedEnv:
             _lib.check(_lib.lib().rsr_batch_set_dr_field(self._batch, fid, C.c_void_p(keep[k].data_ptr())))
         self._dr = keep
 
+    def set_schedule(self, units: int) -> None:
+        """Work units per env-step of the persistent step launch (results are bit-identical for every value)."""
+        _lib.check(_lib.lib().rsr_batch_set_schedule(self._batch, int(units)))
+
     def enable_debug(self, on: bool = True):
         import torch
         if on:

@@ -26,20 +26,30 @@ else:
     dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
     env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
     nu, astd = 5, 1.0
+units = int(sys.argv[sys.argv.index("--units") + 1]) if "--units" in sys.argv else 1
+if hasattr(env, "set_schedule"):
+    env.set_schedule(units)
 s = env.reset(prng.split(prng.PRNGKey(0), n))
 dbg = env.enable_debug(True)
 for t in range(60):
     env.step(s, torch.clamp(torch.randn(n, nu, device="cuda") * astd, -1, 1))
 torch.cuda.synchronize()
-raw = dbg[:, 7300:7307].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+raw = dbg[:, 7300:7300 + 8 * units].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+raw = raw.reshape(n, units, 8).transpose(1, 0, 2).reshape(n * units, 8)        # unit-major: all phase-0 units, then phase 1, ...
 rt0 = raw[:, 0] | (raw[:, 1] << 32); rt1 = raw[:, 2] | (raw[:, 3] << 32)
 cyc = raw[:, 4]; hw = raw[:, 5]; xcc = raw[:, 6] & 0xF
+if units > 1:
+    for ph in range(units):
+        sl = slice(ph * n, (ph + 1) * n)
+        print(f"phase {ph}: unit start {((rt0[sl] - rt0.min()) / 100.0).min():.1f}..{((rt0[sl] - rt0.min()) / 100.0).max():.1f} us, lifetime mean {((rt1[sl] - rt0[sl]) / 100.0).mean():.1f} us, cycles mean {cyc[sl].mean():.0f}")
+    gap = (rt0[n:2 * n] - rt1[:n]) / 100.0
+    print(f"phase 1 start minus phase 0 end of the same env: min {gap.min():.1f} p50 {np.median(gap):.1f} max {gap.max():.1f} us")
 t0 = (rt0 - rt0.min()) / 100.0; t1 = (rt1 - rt0.min()) / 100.0      # microseconds (100 MHz)
 life = t1 - t0
 print(f"envs {n}: makespan {t1.max():.1f} us; first start spread {t0.min():.1f}..{np.percentile(t0, 25):.1f} us (25% of waves)")
 print("wave lifetime us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f mean %.1f" % (life.min(), *np.percentile(life, [10, 50, 90, 99]), life.max(), life.mean()))
 print("wave shader cycles: p50 %.0f mean %.0f max %.0f ; implied clock GHz p50 %.2f" % (np.median(cyc), cyc.mean(), cyc.max(), np.median(cyc / life) / 1e3))
-stats = env.view("stats").cpu().numpy()
+stats = np.tile(env.view("stats").cpu().numpy(), (units, 1))
 ncon = stats[:, 2]
 for lo, hi in ((0, 4), (5, 8), (9, 12), (13, 16), (17, 99)):
     sel = (ncon >= lo) & (ncon <= hi)
@@ -50,7 +60,7 @@ grid = np.linspace(0, t1.max(), 41)
 res = [(np.sum((t0 <= g) & (t1 > g))) for g in grid]
 print("waves in flight at 2.5% steps of the makespan:", " ".join(str(r) for r in res))
 order = np.argsort(t0)
-print("start time of wave rank 2048/4096/6144/8191: " + " ".join(f"{t0[order[min(k, n - 1)]]:.1f}" for k in (2048, 4096, 6144, 8191)))
+print("start time of wave rank 2048/4096/6144/8191: " + " ".join(f"{t0[order[min(k, n * units - 1)]]:.1f}" for k in (2048, 4096, 6144, 8191)))
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; se = (hw >> 13) & 7
 slot = ((xcc * 8 + se) * 16 + cu) * 4 + simd
 u, c = np.unique(slot, return_counts=True)
@@ -60,3 +70,22 @@ for i, sl in enumerate(u):
     busy[i] = life[slot == sl].sum()
 print("per-SIMD sum of wave lifetimes / (2 x makespan): mean %.3f min %.3f max %.3f" % ((busy / (2 * t1.max())).mean(), (busy / (2 * t1.max())).min(), (busy / (2 * t1.max())).max()))
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "timeline.npz"), t0=t0, t1=t1, cyc=cyc, hw=hw, xcc=xcc, stats=stats)
+
+if units > 1:
+    sys.exit(0)
+# ---- how well does the previous step's lifetime predict this step's (longest-first dispatch keyed on it)?
+import heapq
+def _life():
+    r = dbg[:, 7300:7307].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    return ((r[:, 2] | (r[:, 3] << 32)) - (r[:, 0] | (r[:, 1] << 32))) / 100.0, r[:, 4]
+def _sched(L, slots=2048):
+    h = [0.0] * slots; heapq.heapify(h)
+    for l in L:
+        heapq.heappush(h, heapq.heappop(h) + l)
+    return max(h)
+prev, prev_cyc = _life()
+env.step(s, torch.clamp(torch.randn(n, nu, device="cuda") * astd, -1, 1)); torch.cuda.synchronize()
+cur, cur_cyc = _life()
+print(f"lifetime correlation between consecutive steps: {np.corrcoef(prev, cur)[0, 1]:.3f} (cycles: {np.corrcoef(prev_cyc, cur_cyc)[0, 1]:.3f})")
+print(f"simulated makespan of this step's lifetimes on 2048 slots: index order {_sched(cur):.0f} us, longest-first by own lifetime {_sched(np.sort(cur)[::-1]):.0f}, "
+      f"longest-first by the previous step's lifetime {_sched(cur[np.argsort(-prev)]):.0f}, by previous cycles {_sched(cur[np.argsort(-prev_cyc)]):.0f}, ideal {cur.sum() / 2048:.0f}")
