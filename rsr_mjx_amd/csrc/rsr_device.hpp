@@ -384,7 +384,20 @@ enum LaneQuad { LQ_B_IDS = 0, LQ_B_POS, LQ_B_QUAT, LQ_B_JPOS, LQ_B_JAX, LQ_B_IQU
                 LQ_D_IDS, LQ_D_MASKS, LQ_D_ACT, LQ_D_CTRL, LQ_D_BIAS, LQ_D_FRC,
                 LQ_F_0, LQ_F_1, LQ_F_2, LQ_L_0, LQ_L_1, LQ_L_2, LQ_L_3, LQ_P_0, LQ_P_1, LQ_P_2, LQ_P_3, LQ_P_4, LQ_P_5,
                 LQ_E_0, LQ_E_1, LQ_E_2, LQ_E_3, LQ_E_4, LQ_COUNT };
-__device__ __forceinline__ int4 lrec(const DModel& m, int quad, int lane) { return m.lane_rec[quad * 64 + lane]; }
+// number of lanes that hold data in a quad's row (its role's count); the lanes past it hold zeros
+template <class C>
+__device__ __forceinline__ constexpr int lq_count(int quad) {
+  return quad < LQ_J_IDS ? C::NB : quad < LQ_G_POS ? C::NJ : quad < LQ_S_POS ? C::NG : quad < LQ_D_IDS ? C::NS : quad < LQ_F_0 ? C::NV
+       : quad < LQ_L_0 ? C::NF : quad < LQ_P_0 ? C::NL : quad < LQ_E_0 ? C::NP : C::NEQ;
+}
+// Lanes past the role's count all read the first zero entry of the row instead of their own: a row then occupies
+// (count + 1) * 16 bytes of the CU's vector L1 instead of 1 KB, and the whole table ~14 KB instead of 42 KB (the L1 is 32 KB
+// and eight waves in different stages share it).
+template <class C>
+__device__ __forceinline__ int4 lrec(const DModel& m, int quad, int lane) {
+  const int cnt = lq_count<C>(quad) < 63 ? lq_count<C>(quad) : 63;
+  return m.lane_rec[quad * 64 + (lane < cnt ? lane : cnt)];
+}
 // The lane index a stage passes to lrec: `lane` plus a zero the optimiser cannot see through.  The records are loop
 // invariant, and hoisted out of the substep loop they would stay live across the solver, where every register is taken:
 // they would be spilled there and come back from scratch memory instead.
@@ -409,13 +422,13 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
   const int lr = lrec_lane(lane);
   static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64 && C::NS <= 64, "one lane per body / geom / joint / site");
   // every model constant of the stage, for all of this lane's roles
-  const int4 rb_ids = lrec(m, LQ_B_IDS, lr), rb_pos = lrec(m, LQ_B_POS, lr), rb_quat = lrec(m, LQ_B_QUAT, lr);
-  const int4 rb_jpos = lrec(m, LQ_B_JPOS, lr), rb_jax = lrec(m, LQ_B_JAX, lr), rb_iquat = lrec(m, LQ_B_IQUAT, lr);
-  const int4 rb_misc = lrec(m, LQ_B_MISC, lr);
-  const int4 rj_ids = lrec(m, LQ_J_IDS, lr), rj_bquat = lrec(m, LQ_J_BQUAT, lr), rj_bpos = lrec(m, LQ_J_BPOS, lr);
-  const int4 rj_posax = lrec(m, LQ_J_POSAX, lr), rj_ax = lrec(m, LQ_J_AX, lr);
-  const int4 rg_pos = lrec(m, LQ_G_POS, lr), rg_quat = lrec(m, LQ_G_QUAT, lr);
-  const int4 rs_pos = lrec(m, LQ_S_POS, lr), rs_quat = lrec(m, LQ_S_QUAT, lr);
+  const int4 rb_ids = lrec<C>(m, LQ_B_IDS, lr), rb_pos = lrec<C>(m, LQ_B_POS, lr), rb_quat = lrec<C>(m, LQ_B_QUAT, lr);
+  const int4 rb_jpos = lrec<C>(m, LQ_B_JPOS, lr), rb_jax = lrec<C>(m, LQ_B_JAX, lr), rb_iquat = lrec<C>(m, LQ_B_IQUAT, lr);
+  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr);
+  const int4 rj_ids = lrec<C>(m, LQ_J_IDS, lr), rj_bquat = lrec<C>(m, LQ_J_BQUAT, lr), rj_bpos = lrec<C>(m, LQ_J_BPOS, lr);
+  const int4 rj_posax = lrec<C>(m, LQ_J_POSAX, lr), rj_ax = lrec<C>(m, LQ_J_AX, lr);
+  const int4 rg_pos = lrec<C>(m, LQ_G_POS, lr), rg_quat = lrec<C>(m, LQ_G_QUAT, lr);
+  const int4 rs_pos = lrec<C>(m, LQ_S_POS, lr), rs_quat = lrec<C>(m, LQ_S_QUAT, lr);
   const int b = lane < C::NB ? lane : 0;
   const int parent = rb_ids.x, depth = lane < C::NB ? rb_ids.y : -1;
   V3 bp = v3_xyz(rb_pos);
@@ -583,8 +596,8 @@ __device__ __forceinline__ void chain_sum_quad(const Smem<C>& s, const float* ve
 template <class C>
 __device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
   const int lr = lrec_lane(lane);
-  const int4 rb_misc = lrec(m, LQ_B_MISC, lr), rb_inertia = lrec(m, LQ_B_INERTIA, lr);
-  const int4 rd_ids = lrec(m, LQ_D_IDS, lr), rd_masks = lrec(m, LQ_D_MASKS, lr);
+  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr), rb_inertia = lrec<C>(m, LQ_B_INERTIA, lr);
+  const int4 rd_ids = lrec<C>(m, LQ_D_IDS, lr), rd_masks = lrec<C>(m, LQ_D_MASKS, lr);
   const int max_sub = m.max_sub, max_chain = m.max_chain;
   // subtree mask of body lane / 4 for the four-lanes-per-body composite inertia sum below (body b's mask sits in lane b's
   // record; a cross-lane read needs its source lane active, so it is fetched here in uniform code)
@@ -1102,7 +1115,7 @@ __device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane 
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
   const int lr = lrec_lane(lane);
-  const int4 rp0 = lrec(m, LQ_P_0, lr), rp1 = lrec(m, LQ_P_1, lr), rp2 = lrec(m, LQ_P_2, lr);
+  const int4 rp0 = lrec<C>(m, LQ_P_0, lr), rp1 = lrec<C>(m, LQ_P_1, lr), rp2 = lrec<C>(m, LQ_P_2, lr);
   if (lane < C::NP) {
     const int g1 = rp0.x, g2 = rp0.y, kind = rp0.z;
     incl = asf(rp0.w);
@@ -1177,13 +1190,13 @@ struct Q6 { float qd; float c[6]; };      // one chain dof: its velocity and a s
 template <class C>
 __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
   const int lr = lrec_lane(lane);
-  const int4 rb_misc = lrec(m, LQ_B_MISC, lr), rd_ids = lrec(m, LQ_D_IDS, lr), rd_masks = lrec(m, LQ_D_MASKS, lr);
-  const int4 rd_act = lrec(m, LQ_D_ACT, lr), rd_ctrl = lrec(m, LQ_D_CTRL, lr), rd_bias = lrec(m, LQ_D_BIAS, lr), rd_frc = lrec(m, LQ_D_FRC, lr);
+  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr), rd_ids = lrec<C>(m, LQ_D_IDS, lr), rd_masks = lrec<C>(m, LQ_D_MASKS, lr);
+  const int4 rd_act = lrec<C>(m, LQ_D_ACT, lr), rd_ctrl = lrec<C>(m, LQ_D_CTRL, lr), rd_bias = lrec<C>(m, LQ_D_BIAS, lr), rd_frc = lrec<C>(m, LQ_D_FRC, lr);
   const int max_sub = m.max_sub, max_chain = m.max_chain;
   const float grav0 = m.gravity[0], grav1 = m.gravity[1], grav2 = m.gravity[2];
   const int qb = lane >> 2;            // four lanes per body for the subtree force sums below (see com_crb_mass)
   const unsigned frc_mask_q = (unsigned)__shfl(rb_misc.z, qb < C::NB ? qb : 0);
-  const int site_b = lrec(m, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
+  const int site_b = lrec<C>(m, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
   int xfrc_b = 0, xfrc_root = 0; unsigned xfrc_dofs = 0u;
   if constexpr (C::XFRC) {
     xfrc_b = s.xfrc_body;
@@ -1328,9 +1341,9 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
                                int& nbase_out PROF_ARG) {
   constexpr int LD = C::LDJ;      // every LD below strides the Jacobian
   const int lr = lrec_lane(lane);
-  const int4 rl0 = lrec(m, LQ_L_0, lr), rl1 = lrec(m, LQ_L_1, lr);
-  const int4 re0 = lrec(m, LQ_E_0, lr), re1 = lrec(m, LQ_E_1, lr), re2 = lrec(m, LQ_E_2, lr), re3 = lrec(m, LQ_E_3, lr), re4 = lrec(m, LQ_E_4, lr);
-  const int4 rf0 = lrec(m, LQ_F_0, lr), rf1 = lrec(m, LQ_F_1, lr), rf2 = lrec(m, LQ_F_2, lr);
+  const int4 rl0 = lrec<C>(m, LQ_L_0, lr), rl1 = lrec<C>(m, LQ_L_1, lr);
+  const int4 re0 = lrec<C>(m, LQ_E_0, lr), re1 = lrec<C>(m, LQ_E_1, lr), re2 = lrec<C>(m, LQ_E_2, lr), re3 = lrec<C>(m, LQ_E_3, lr), re4 = lrec<C>(m, LQ_E_4, lr);
+  const int4 rf0 = lrec<C>(m, LQ_F_0, lr), rf1 = lrec<C>(m, LQ_F_1, lr), rf2 = lrec<C>(m, LQ_F_2, lr);
   // active joint limits, compacted in slot order (slot = index into limit_jnts; its constants are record LQ_L_*[slot])
   int lim_active = 0;
   if (lane < C::NL) {
@@ -1363,7 +1376,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + rf0.x] = 1.0f; s.sdof[r_fric + lane] = rf0.x; }
   if (lane < nl) {
     const int sl = s.lim_jnt[lane];
-    const int4 q0 = lrec(m, LQ_L_0, sl);
+    const int4 q0 = lrec<C>(m, LQ_L_0, sl);
     float q = s.qpos[q0.x];
     float dmin = q - asf(q0.z), dmax = asf(q0.w) - q;
     s.x.b.J[(r_lim + lane) * LD + q0.y] = dmin < dmax ? 1.0f : -1.0f;
@@ -1374,7 +1387,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
     int p = s.cpair[c];
-    const int4 rp3 = lrec(m, LQ_P_3, p);
+    const int4 rp3 = lrec<C>(m, LQ_P_3, p);
     V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
     make_frame(n, nn, t1, t2);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
@@ -1391,7 +1404,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   for (int t = lane; t < ncon * C::NBC; t += 64) {
     int c = t / C::NBC, k = t - c * C::NBC;
     int p = s.cpair[c];
-    const int4 rp0 = lrec(m, LQ_P_0, p), rp2 = lrec(m, LQ_P_2, p);
+    const int4 rp0 = lrec<C>(m, LQ_P_0, p), rp2 = lrec<C>(m, LQ_P_2, p);
     const int g1 = rp0.x, g2 = rp0.y, rule = rp2.w;       // rule: 0 = max of the two geoms, 1 / 2 = the higher-priority geom's
     float a0 = s.fric[3 * g1], a1 = s.fric[3 * g1 + 1], b0 = s.fric[3 * g2], b1 = s.fric[3 * g2 + 1];
     float f0 = rule == 0 ? fmaxf(a0, b0) : (rule == 1 ? a0 : b0), f1 = rule == 0 ? fmaxf(a1, b1) : (rule == 1 ? a1 : b1);
@@ -1415,20 +1428,20 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
         si.v[0] = asf(re3.w); si.v[1] = asf(re4.x); si.v[2] = asf(re4.y); si.v[3] = asf(re4.z); si.v[4] = asf(re4.w);
       } else if (r < r_lim) {                // friction row: slot r - r_fric
         const int sl = r - r_fric;
-        const int4 q0 = lrec(m, LQ_F_0, sl), q1 = lrec(m, LQ_F_1, sl), q2 = lrec(m, LQ_F_2, sl);
+        const int4 q0 = lrec<C>(m, LQ_F_0, sl), q1 = lrec<C>(m, LQ_F_1, sl), q2 = lrec<C>(m, LQ_F_2, sl);
         invw = asf(q0.y); sr0 = asf(q0.z); sr1 = asf(q0.w);
         si.v[0] = asf(q1.x); si.v[1] = asf(q1.y); si.v[2] = asf(q1.z); si.v[3] = asf(q1.w); si.v[4] = asf(q2.x);
         fl = s.floss[q0.x];
       } else if (r < r_con) {                // active limit: slot from the compaction
         const int sl = s.lim_jnt[r - r_lim];
-        const int4 q0 = lrec(m, LQ_L_0, sl), q1 = lrec(m, LQ_L_1, sl), q2 = lrec(m, LQ_L_2, sl), q3 = lrec(m, LQ_L_3, sl);
+        const int4 q0 = lrec<C>(m, LQ_L_0, sl), q1 = lrec<C>(m, LQ_L_1, sl), q2 = lrec<C>(m, LQ_L_2, sl), q3 = lrec<C>(m, LQ_L_3, sl);
         float q = s.qpos[q0.x];
         pos = fminf(q - asf(q0.z), asf(q0.w) - q) - asf(q1.x);
         invw = asf(q1.y); sr0 = asf(q1.z); sr1 = asf(q1.w);
         si.v[0] = asf(q2.x); si.v[1] = asf(q2.y); si.v[2] = asf(q2.z); si.v[3] = asf(q2.w); si.v[4] = asf(q3.x);
       } else {
         int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c];
-        const int4 q0 = lrec(m, LQ_P_0, p), q1 = lrec(m, LQ_P_1, p), q4 = lrec(m, LQ_P_4, p), q5 = lrec(m, LQ_P_5, p);
+        const int4 q0 = lrec<C>(m, LQ_P_0, p), q1 = lrec<C>(m, LQ_P_1, p), q4 = lrec<C>(m, LQ_P_4, p), q5 = lrec<C>(m, LQ_P_5, p);
         pos = s.cdist[c] - asf(q0.w);
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
 // ---------------------------------------------------------------- Go2 step kernel (joystick.py:204-280 + wrappers)
 template <class C>
 #ifndef RSR_GO2_WAVES_PER_EU
-#define RSR_GO2_WAVES_PER_EU 2
+#define RSR_GO2_WAVES_PER_EU 3
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_GO2_WAVES_PER_EU, RSR_GO2_WAVES_PER_EU)))
 void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {

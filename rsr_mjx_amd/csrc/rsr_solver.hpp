@@ -593,7 +593,7 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
 template <class C>
 __device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
   const int lr = lrec_lane(lane);
-  const int4 rj_ids = lrec(m, LQ_J_IDS, lr), rj_ax = lrec(m, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
+  const int4 rj_ids = lrec<C>(m, LQ_J_IDS, lr), rj_ax = lrec<C>(m, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
   float qacc = f.qacc;
   const bool implicit = implicit_integration<C>(m, s, lane);
   if (implicit) {
