@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
 #define RSR_PERSISTENT 1             // 1: a wave loops over tickets; 0: one ticket per workgroup, grid = units * n (measured: DESIGN.md 4)
 #endif
 #ifndef RSR_DEFAULT_UNITS
-#define RSR_DEFAULT_UNITS 2          // phases per env-step of the work-queue dispatch (measured: DESIGN.md 4)
+#define RSR_DEFAULT_UNITS 4          // phases per env-step of the work-queue dispatch (measured: DESIGN.md 4)
 #endif
 template <class C, int ENV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
