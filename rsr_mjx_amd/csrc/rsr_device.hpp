@@ -67,6 +67,25 @@ struct DModel {
   int env_kind, n_frames, episode_length, wrap_flags;
 };
 
+// The model's scalars of the hot path and the lane-record pointer, read once at kernel start.  The DModel is passed by
+// pointer (its ~180 pointers would otherwise sit in SGPRs), so every m.x in a stage is a scalar load from memory with its own
+// wait, and every stage's record fetch first loads m.lane_rec; a wave reads these few dozen times per substep.  Held in
+// SGPRs (or spilled to VGPR lanes, still ~10x cheaper than the load).
+struct Hot {
+  const int4* lane_rec;
+  float timestep, grav0, grav1, grav2, impratio, tolerance, ls_tolerance, meaninertia;
+  int maxdepth, max_sub, max_chain, integrator, disable_eulerdamp, disable_refsafe, iterations, ls_iterations, n_frames;
+};
+__device__ __forceinline__ Hot make_hot(const DModel& m) {
+  Hot h;
+  h.lane_rec = m.lane_rec; h.timestep = m.timestep; h.grav0 = m.gravity[0]; h.grav1 = m.gravity[1]; h.grav2 = m.gravity[2];
+  h.impratio = m.impratio; h.tolerance = m.tolerance; h.ls_tolerance = m.ls_tolerance; h.meaninertia = m.meaninertia;
+  h.maxdepth = m.maxdepth; h.max_sub = m.max_sub; h.max_chain = m.max_chain; h.integrator = m.integrator;
+  h.disable_eulerdamp = m.disable_eulerdamp; h.disable_refsafe = m.disable_refsafe; h.iterations = m.iterations;
+  h.ls_iterations = m.ls_iterations; h.n_frames = m.n_frames;
+  return h;
+}
+
 // ---- record layout (floats per env); offsets filled on the host, see rsr_mjx.hip ----
 struct Layout {
   int qpos, qvel, ctrl, warm, time, xpos, site_xpos;
@@ -288,7 +307,7 @@ __device__ __forceinline__ void prof_timeline(float* d, unsigned long long rt0, 
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
-       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_COUNT };
+       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_L_PREP, PS_L_P0, PS_L_LO, PS_L_ITER, PS_U_JTF, PS_S_COST, PS_S_JTF, PS_COUNT };
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
@@ -394,9 +413,9 @@ __device__ __forceinline__ constexpr int lq_count(int quad) {
 // (count + 1) * 16 bytes of the CU's vector L1 instead of 1 KB, and the whole table ~14 KB instead of 42 KB (the L1 is 32 KB
 // and eight waves in different stages share it).
 template <class C>
-__device__ __forceinline__ int4 lrec(const DModel& m, int quad, int lane) {
+__device__ __forceinline__ int4 lrec(const Hot& h, int quad, int lane) {
   const int cnt = lq_count<C>(quad) < 63 ? lq_count<C>(quad) : 63;
-  return m.lane_rec[quad * 64 + (lane < cnt ? lane : cnt)];
+  return h.lane_rec[quad * 64 + (lane < cnt ? lane : cnt)];
 }
 // The lane index a stage passes to lrec: `lane` plus a zero the optimiser cannot see through.  The records are loop
 // invariant, and hoisted out of the substep loop they would stay live across the solver, where every register is taken:
@@ -418,17 +437,17 @@ __device__ __forceinline__ Q4 q4_of(int4 r) { return Q4{asf(r.x), asf(r.y), asf(
 // register-only steps instead of nbody LDS round trips.  Bodies carry at most one joint (checked on the host).
 // =====================================================================================
 template <class C>
-__device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C>& s, int lane) {
   const int lr = lrec_lane(lane);
   static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64 && C::NS <= 64, "one lane per body / geom / joint / site");
   // every model constant of the stage, for all of this lane's roles
-  const int4 rb_ids = lrec<C>(m, LQ_B_IDS, lr), rb_pos = lrec<C>(m, LQ_B_POS, lr), rb_quat = lrec<C>(m, LQ_B_QUAT, lr);
-  const int4 rb_jpos = lrec<C>(m, LQ_B_JPOS, lr), rb_jax = lrec<C>(m, LQ_B_JAX, lr), rb_iquat = lrec<C>(m, LQ_B_IQUAT, lr);
-  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr);
-  const int4 rj_ids = lrec<C>(m, LQ_J_IDS, lr), rj_bquat = lrec<C>(m, LQ_J_BQUAT, lr), rj_bpos = lrec<C>(m, LQ_J_BPOS, lr);
-  const int4 rj_posax = lrec<C>(m, LQ_J_POSAX, lr), rj_ax = lrec<C>(m, LQ_J_AX, lr);
-  const int4 rg_pos = lrec<C>(m, LQ_G_POS, lr), rg_quat = lrec<C>(m, LQ_G_QUAT, lr);
-  const int4 rs_pos = lrec<C>(m, LQ_S_POS, lr), rs_quat = lrec<C>(m, LQ_S_QUAT, lr);
+  const int4 rb_ids = lrec<C>(h, LQ_B_IDS, lr), rb_pos = lrec<C>(h, LQ_B_POS, lr), rb_quat = lrec<C>(h, LQ_B_QUAT, lr);
+  const int4 rb_jpos = lrec<C>(h, LQ_B_JPOS, lr), rb_jax = lrec<C>(h, LQ_B_JAX, lr), rb_iquat = lrec<C>(h, LQ_B_IQUAT, lr);
+  const int4 rb_misc = lrec<C>(h, LQ_B_MISC, lr);
+  const int4 rj_ids = lrec<C>(h, LQ_J_IDS, lr), rj_bquat = lrec<C>(h, LQ_J_BQUAT, lr), rj_bpos = lrec<C>(h, LQ_J_BPOS, lr);
+  const int4 rj_posax = lrec<C>(h, LQ_J_POSAX, lr), rj_ax = lrec<C>(h, LQ_J_AX, lr);
+  const int4 rg_pos = lrec<C>(h, LQ_G_POS, lr), rg_quat = lrec<C>(h, LQ_G_QUAT, lr);
+  const int4 rs_pos = lrec<C>(h, LQ_S_POS, lr), rs_quat = lrec<C>(h, LQ_S_QUAT, lr);
   const int b = lane < C::NB ? lane : 0;
   const int parent = rb_ids.x, depth = lane < C::NB ? rb_ids.y : -1;
   V3 bp = v3_xyz(rb_pos);
@@ -463,7 +482,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, Smem<C>& s, int lane
   // compose down the tree: after level d every body of depth <= d holds its world pose
   V3 pos = lane == 0 ? v3(0, 0, 0) : lp;
   Q4 q = lane == 0 ? Q4{1, 0, 0, 0} : lq;
-  for (int d = 1; d <= m.maxdepth; ++d) {
+  for (int d = 1; d <= h.maxdepth; ++d) {
     V3 pp = v3(__shfl(pos.x, parent), __shfl(pos.y, parent), __shfl(pos.z, parent));
     Q4 pq = Q4{__shfl(q.w, parent), __shfl(q.x, parent), __shfl(q.y, parent), __shfl(q.z, parent)};
     if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
@@ -594,11 +613,11 @@ __device__ __forceinline__ void chain_sum_quad(const Smem<C>& s, const float* ve
 // stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
 // =====================================================================================
 template <class C>
-__device__ __forceinline__ void com_crb_mass(const DModel& m, Smem<C>& s, int lane) {
+__device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem<C>& s, int lane) {
   const int lr = lrec_lane(lane);
-  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr), rb_inertia = lrec<C>(m, LQ_B_INERTIA, lr);
-  const int4 rd_ids = lrec<C>(m, LQ_D_IDS, lr), rd_masks = lrec<C>(m, LQ_D_MASKS, lr);
-  const int max_sub = m.max_sub, max_chain = m.max_chain;
+  const int4 rb_misc = lrec<C>(h, LQ_B_MISC, lr), rb_inertia = lrec<C>(h, LQ_B_INERTIA, lr);
+  const int4 rd_ids = lrec<C>(h, LQ_D_IDS, lr), rd_masks = lrec<C>(h, LQ_D_MASKS, lr);
+  const int max_sub = h.max_sub, max_chain = h.max_chain;
   // subtree mask of body lane / 4 for the four-lanes-per-body composite inertia sum below (body b's mask sits in lane b's
   // record; a cross-lane read needs its source lane active, so it is fetched here in uniform code)
   const int qb = lane >> 2;
@@ -1110,12 +1129,12 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
 }
 
 template <class C>
-__device__ __forceinline__ void collision(const DModel& m, Smem<C>& s, int lane PROF_ARG) {
+__device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>& s, int lane PROF_ARG) {
   CPts pts; pts.cnt = 0;
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
   const int lr = lrec_lane(lane);
-  const int4 rp0 = lrec<C>(m, LQ_P_0, lr), rp1 = lrec<C>(m, LQ_P_1, lr), rp2 = lrec<C>(m, LQ_P_2, lr);
+  const int4 rp0 = lrec<C>(h, LQ_P_0, lr), rp1 = lrec<C>(h, LQ_P_1, lr), rp2 = lrec<C>(h, LQ_P_2, lr);
   if (lane < C::NP) {
     const int g1 = rp0.x, g2 = rp0.y, kind = rp0.z;
     incl = asf(rp0.w);
@@ -1188,15 +1207,15 @@ __device__ __forceinline__ void motion_cross(float* o, const float* u, const flo
 
 struct Q6 { float qd; float c[6]; };      // one chain dof: its velocity and a spatial vector
 template <class C>
-__device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
+__device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
   const int lr = lrec_lane(lane);
-  const int4 rb_misc = lrec<C>(m, LQ_B_MISC, lr), rd_ids = lrec<C>(m, LQ_D_IDS, lr), rd_masks = lrec<C>(m, LQ_D_MASKS, lr);
-  const int4 rd_act = lrec<C>(m, LQ_D_ACT, lr), rd_ctrl = lrec<C>(m, LQ_D_CTRL, lr), rd_bias = lrec<C>(m, LQ_D_BIAS, lr), rd_frc = lrec<C>(m, LQ_D_FRC, lr);
-  const int max_sub = m.max_sub, max_chain = m.max_chain;
-  const float grav0 = m.gravity[0], grav1 = m.gravity[1], grav2 = m.gravity[2];
+  const int4 rb_misc = lrec<C>(h, LQ_B_MISC, lr), rd_ids = lrec<C>(h, LQ_D_IDS, lr), rd_masks = lrec<C>(h, LQ_D_MASKS, lr);
+  const int4 rd_act = lrec<C>(h, LQ_D_ACT, lr), rd_ctrl = lrec<C>(h, LQ_D_CTRL, lr), rd_bias = lrec<C>(h, LQ_D_BIAS, lr), rd_frc = lrec<C>(h, LQ_D_FRC, lr);
+  const int max_sub = h.max_sub, max_chain = h.max_chain;
+  const float grav0 = h.grav0, grav1 = h.grav1, grav2 = h.grav2;
   const int qb = lane >> 2;            // four lanes per body for the subtree force sums below (see com_crb_mass)
   const unsigned frc_mask_q = (unsigned)__shfl(rb_misc.z, qb < C::NB ? qb : 0);
-  const int site_b = lrec<C>(m, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
+  const int site_b = lrec<C>(h, LQ_S_POS, lr).x, site_root = __shfl(rb_misc.y, site_b);   // lanes >= NS: body 0
   int xfrc_b = 0, xfrc_root = 0; unsigned xfrc_dofs = 0u;
   if constexpr (C::XFRC) {
     xfrc_b = s.xfrc_body;
@@ -1310,7 +1329,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, Smem<C>& s, int 
 struct RowRegs { float aref, D, R, floss, mu; int bn, bk; };
 
 struct Solimp { float v[5]; };
-__device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const Solimp& sip, float pos, float& k, float& b, float& imp) {
+__device__ __forceinline__ void kbi(const Hot& m, float sr0, float sr1, const Solimp& sip, float pos, float& k, float& b, float& imp) {
   const float* si = sip.v;
   float timeconst = sr0, dampratio = sr1;
   if (!m.disable_refsafe) timeconst = fmaxf(timeconst, 2.0f * m.timestep);
@@ -1337,13 +1356,13 @@ __device__ __forceinline__ void kbi(const DModel& m, float sr0, float sr1, const
 // Returns nefc; rr[] holds the per-row scalars except the velocity part of aref: the caller finishes
 // aref -= bcoef * (J.qvel) once the base rows are in LDS (it owns the J.v machinery).
 template <class C>
-__device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
+__device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Smem<C>& s, int lane, RowRegs (&rr)[C::NCHUNK], float (&bcoef)[C::NCHUNK],
                                int& nbase_out PROF_ARG) {
   constexpr int LD = C::LDJ;      // every LD below strides the Jacobian
   const int lr = lrec_lane(lane);
-  const int4 rl0 = lrec<C>(m, LQ_L_0, lr), rl1 = lrec<C>(m, LQ_L_1, lr);
-  const int4 re0 = lrec<C>(m, LQ_E_0, lr), re1 = lrec<C>(m, LQ_E_1, lr), re2 = lrec<C>(m, LQ_E_2, lr), re3 = lrec<C>(m, LQ_E_3, lr), re4 = lrec<C>(m, LQ_E_4, lr);
-  const int4 rf0 = lrec<C>(m, LQ_F_0, lr), rf1 = lrec<C>(m, LQ_F_1, lr), rf2 = lrec<C>(m, LQ_F_2, lr);
+  const int4 rl0 = lrec<C>(h, LQ_L_0, lr), rl1 = lrec<C>(h, LQ_L_1, lr);
+  const int4 re0 = lrec<C>(h, LQ_E_0, lr), re1 = lrec<C>(h, LQ_E_1, lr), re2 = lrec<C>(h, LQ_E_2, lr), re3 = lrec<C>(h, LQ_E_3, lr), re4 = lrec<C>(h, LQ_E_4, lr);
+  const int4 rf0 = lrec<C>(h, LQ_F_0, lr), rf1 = lrec<C>(h, LQ_F_1, lr), rf2 = lrec<C>(h, LQ_F_2, lr);
   // active joint limits, compacted in slot order (slot = index into limit_jnts; its constants are record LQ_L_*[slot])
   int lim_active = 0;
   if (lane < C::NL) {
@@ -1376,7 +1395,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + rf0.x] = 1.0f; s.sdof[r_fric + lane] = rf0.x; }
   if (lane < nl) {
     const int sl = s.lim_jnt[lane];
-    const int4 q0 = lrec<C>(m, LQ_L_0, sl);
+    const int4 q0 = lrec<C>(h, LQ_L_0, sl);
     float q = s.qpos[q0.x];
     float dmin = q - asf(q0.z), dmax = asf(q0.w) - q;
     s.x.b.J[(r_lim + lane) * LD + q0.y] = dmin < dmax ? 1.0f : -1.0f;
@@ -1387,7 +1406,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
     int p = s.cpair[c];
-    const int4 rp3 = lrec<C>(m, LQ_P_3, p);
+    const int4 rp3 = lrec<C>(h, LQ_P_3, p);
     V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
     make_frame(n, nn, t1, t2);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
@@ -1404,7 +1423,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
   for (int t = lane; t < ncon * C::NBC; t += 64) {
     int c = t / C::NBC, k = t - c * C::NBC;
     int p = s.cpair[c];
-    const int4 rp0 = lrec<C>(m, LQ_P_0, p), rp2 = lrec<C>(m, LQ_P_2, p);
+    const int4 rp0 = lrec<C>(h, LQ_P_0, p), rp2 = lrec<C>(h, LQ_P_2, p);
     const int g1 = rp0.x, g2 = rp0.y, rule = rp2.w;       // rule: 0 = max of the two geoms, 1 / 2 = the higher-priority geom's
     float a0 = s.fric[3 * g1], a1 = s.fric[3 * g1 + 1], b0 = s.fric[3 * g2], b1 = s.fric[3 * g2 + 1];
     float f0 = rule == 0 ? fmaxf(a0, b0) : (rule == 1 ? a0 : b0), f1 = rule == 0 ? fmaxf(a1, b1) : (rule == 1 ? a1 : b1);
@@ -1428,31 +1447,31 @@ __device__ __forceinline__ int make_constraint(const DModel& m, Smem<C>& s, int 
         si.v[0] = asf(re3.w); si.v[1] = asf(re4.x); si.v[2] = asf(re4.y); si.v[3] = asf(re4.z); si.v[4] = asf(re4.w);
       } else if (r < r_lim) {                // friction row: slot r - r_fric
         const int sl = r - r_fric;
-        const int4 q0 = lrec<C>(m, LQ_F_0, sl), q1 = lrec<C>(m, LQ_F_1, sl), q2 = lrec<C>(m, LQ_F_2, sl);
+        const int4 q0 = lrec<C>(h, LQ_F_0, sl), q1 = lrec<C>(h, LQ_F_1, sl), q2 = lrec<C>(h, LQ_F_2, sl);
         invw = asf(q0.y); sr0 = asf(q0.z); sr1 = asf(q0.w);
         si.v[0] = asf(q1.x); si.v[1] = asf(q1.y); si.v[2] = asf(q1.z); si.v[3] = asf(q1.w); si.v[4] = asf(q2.x);
         fl = s.floss[q0.x];
       } else if (r < r_con) {                // active limit: slot from the compaction
         const int sl = s.lim_jnt[r - r_lim];
-        const int4 q0 = lrec<C>(m, LQ_L_0, sl), q1 = lrec<C>(m, LQ_L_1, sl), q2 = lrec<C>(m, LQ_L_2, sl), q3 = lrec<C>(m, LQ_L_3, sl);
+        const int4 q0 = lrec<C>(h, LQ_L_0, sl), q1 = lrec<C>(h, LQ_L_1, sl), q2 = lrec<C>(h, LQ_L_2, sl), q3 = lrec<C>(h, LQ_L_3, sl);
         float q = s.qpos[q0.x];
         pos = fminf(q - asf(q0.z), asf(q0.w) - q) - asf(q1.x);
         invw = asf(q1.y); sr0 = asf(q1.z); sr1 = asf(q1.w);
         si.v[0] = asf(q2.x); si.v[1] = asf(q2.y); si.v[2] = asf(q2.z); si.v[3] = asf(q2.w); si.v[4] = asf(q3.x);
       } else {
         int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c];
-        const int4 q0 = lrec<C>(m, LQ_P_0, p), q1 = lrec<C>(m, LQ_P_1, p), q4 = lrec<C>(m, LQ_P_4, p), q5 = lrec<C>(m, LQ_P_5, p);
+        const int4 q0 = lrec<C>(h, LQ_P_0, p), q1 = lrec<C>(h, LQ_P_1, p), q4 = lrec<C>(h, LQ_P_4, p), q5 = lrec<C>(h, LQ_P_5, p);
         pos = s.cdist[c] - asf(q0.w);
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];
         o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
         float tw = asf(q1.w);
-        invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / m.impratio;
+        invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / h.impratio;
         sr0 = asf(q4.x); sr1 = asf(q4.y);
         si.v[0] = asf(q4.z); si.v[1] = asf(q4.w); si.v[2] = asf(q5.x); si.v[3] = asf(q5.y); si.v[4] = asf(q5.z);
       }
       float k, b, imp;
-      kbi(m, sr0, sr1, si, pos, k, b, imp);
+      kbi(h, sr0, sr1, si, pos, k, b, imp);
       float R = fmaxf(invw * (1.0f - imp) / imp, RSR_MINVAL);
       o.R = R; o.D = 1.0f / R; o.floss = fl;
       o.aref = -k * imp * pos;        // the caller subtracts b * (J.qvel)

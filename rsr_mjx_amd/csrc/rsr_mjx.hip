@@ -246,6 +246,7 @@ __device__ float go2_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& 
 template <class C, int ENV>
 __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
+  const Hot hot = make_hot(m);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   float Mrow[C::NV], warm = 0.0f;
   FwdOut<C> f;
   PROF_DECL
-  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
+  forward<C>(m, hot, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
   WSYNC();
   if (lane < C::NU) s.ctrl[lane] = ctrl_init;                 // data.replace(ctrl=joint_ctrl), no re-forward
   WSYNC();
@@ -357,6 +358,7 @@ template <class C, int ENV>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_WAVES_PER_EU, RSR_WAVES_PER_EU)))
 void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) {
   const DModel& m = *mp;
+  const Hot hot = make_hot(m);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int lane = threadIdx.x;
@@ -439,7 +441,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   // ---- n_frames x mjx.step ----
   float Mrow[C::NV];
   FwdOut<C> f;
-  for (int fr = phase * m.n_frames / units; fr < (phase + 1) * m.n_frames / units; ++fr) {
+  for (int fr = phase * hot.n_frames / units; fr < (phase + 1) * hot.n_frames / units; ++fr) {
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
 #else
@@ -448,9 +450,9 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
     // the lane index passes through an opaque zero per substep: values derived from it (masks, LDS addresses) are then
     // recomputed in each substep instead of being hoisted out of the loop, kept live across the solver and spilled
     const int lane_s = lrec_lane(lane);
-    forward<C>(m, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
-    integrate<C>(m, s, lane_s, Mrow, f PROF_PASS);
-    time += m.timestep;
+    forward<C>(m, hot, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
+    time += hot.timestep;
   }
   if (!last) {
     // hand the pipeline state to the next phase: write-through stores, drained, then the flag (one wave = one workgroup)
@@ -596,6 +598,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
 template <class C>
 __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
+  const Hot hot = make_hot(m);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
   float Mrow[C::NV], warm = 0.0f;
   FwdOut<C> f;
   PROF_DECL
-  forward<C>(m, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
+  forward<C>(m, hot, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
   WSYNC();
   tf_split<4>(rng0, rng1, bits, lane, ks); rng0 = ks[0][0]; rng1 = ks[0][1];
   {
@@ -697,6 +700,7 @@ template <class C>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_GO2_WAVES_PER_EU, RSR_GO2_WAVES_PER_EU)))
 void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
+  const Hot hot = make_hot(m);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -788,9 +792,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
 #endif
     const int lane_s = lrec_lane(lane);        // see step_kernel
-    forward<C>(m, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
-    integrate<C>(m, s, lane_s, Mrow, f PROF_PASS);
-    time += m.timestep;
+    forward<C>(m, hot, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
+    time += hot.timestep;
   }
   // ---- sensors of the last forward pass, IMU FIFOs (:220-235) ----
   G2Sens sn;

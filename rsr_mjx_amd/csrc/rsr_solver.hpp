@@ -315,7 +315,7 @@ struct SolveStats { int niter, ls_total; };
 // Whether integrate() will solve (M + dt*D) qacc = qfrc_smooth + qfrc_constraint (implicitfast, or Euler with damping
 // folded in): the only consumer of qfrc_constraint on the path.  Wave-uniform.
 template <class C>
-__device__ __forceinline__ bool implicit_integration(const DModel& m, const Smem<C>& s, int lane) {
+__device__ __forceinline__ bool implicit_integration(const Hot& m, const Smem<C>& s, int lane) {
   bool implicit = m.integrator == INT_IMPLICITFAST;
   if (m.integrator == INT_EULER && !m.disable_eulerdamp) {
     float dm = lane < C::NV ? fabsf(s.damp[lane]) : 0.0f;
@@ -327,7 +327,7 @@ __device__ __forceinline__ bool implicit_integration(const DModel& m, const Smem
 // Newton solve.  In: Mrow (row i of M in lane i), fs = qfrc_smooth_i, a0 = qacc_smooth_i, warm_i.
 // Out: qacc_i, qfrc_constraint_i.
 template <class C>
-__device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
+__device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
                       const float (&Mrow)[C::NV], float fs, float a0, float warm, bool need_force, float& qacc_out, float& qfc_out,
                       SolveStats& st PROF_ARG) {
   const bool dofl = lane < C::NV;
@@ -361,10 +361,15 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     gauss = 0.0f;
   }
   cost = rc + gauss;
+  PROF(PS_S_COST)
   float qfc = jt_force<C>(s, lane, nefc, nbase, force);
   float grad = dofl ? Ma - fs - qfc : 0.0f;
-  PROF(PS_SOLVE_INIT)
-  const float scale = 1.0f / (m.meaninertia * (float)(C::NV > 1 ? C::NV : 1));
+  PROF(PS_S_JTF)
+  // the solver's options, fetched once: read where they are used, each is a scalar load from the model struct with its own
+  // wait (the struct is passed by pointer so that its ~180 pointers do not sit in SGPRs), a dozen per Newton iteration
+  const int opt_iterations = m.iterations, opt_ls_iterations = m.ls_iterations;
+  const float opt_tolerance = m.tolerance, opt_ls_tolerance = m.ls_tolerance, opt_meaninertia = m.meaninertia;
+  const float scale = 1.0f / (opt_meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
   float dinv = 0.0f, hw_fact[C::NCHUNK];
   bool have_factor = false;
@@ -372,11 +377,11 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
   for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = 0.0f;
   while (true) {
     bool done;
-    if (m.iterations != 1) {
+    if (opt_iterations != 1) {
       float gn = sqrtf(wave_sum(grad * grad));
-      done = iter >= m.iterations;
-      done |= scale * (prev_cost - cost) < m.tolerance;
-      done |= scale * gn < m.tolerance;
+      done = iter >= opt_iterations;
+      done |= scale * (prev_cost - cost) < opt_tolerance;
+      done |= scale * gn < opt_tolerance;
     } else done = iter >= 1;
     if (uniform_i(done)) break;
     // Newton direction at the current point.  MJX's loop body ends with _update_gradient (gradient, Hessian, factor,
@@ -403,7 +408,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     float snorm = search * search, g1a = search * Ma, g1b = search * fs;
     wave_sum3(snorm, g1a, g1b);
     snorm = sqrtf(snorm);
-    float gtol = m.tolerance * m.ls_tolerance * snorm * m.meaninertia * (float)(C::NV > 1 ? C::NV : 1);
+    float gtol = opt_tolerance * opt_ls_tolerance * snorm * opt_meaninertia * (float)(C::NV > 1 ? C::NV : 1);
     float g1 = g1a - g1b;
     // fp32 noise floor of the 1-D derivative: d0(alpha) = 2 alpha q2 + q1 is a sum of up to NEFC terms, so values
     // below eps * (sum |q1 terms| + 2 |alpha| sum |q2 terms|) are indistinguishable from zero.  MJX's gtol
@@ -423,13 +428,16 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     n1 = (n1 + n1a) + n1b;
     n2 += fabsf(g2);
     // Only for converging solves: with iterations == 1 (Go2) the reference's truncated procedure IS the answer.
-    const float NOISE = m.iterations > 1 ? 1.1920929e-7f : 0.0f;
+    const float NOISE = opt_iterations > 1 ? 1.1920929e-7f : 0.0f;
     PROF(PS_LS_SETUP)
     LSRows<C> lw;
     ls_prepare<C>(lane, nefc, jaref, jv, rr, lw);
+    PROF(PS_L_PREP)
     LSPoint p0 = ls_point<C>(nefc, 0.0f, lw, gauss, g1, g2);
+    PROF(PS_L_P0)
     LSPoint lo = ls_point<C>(nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), lw, gauss, g1, g2), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    PROF(PS_L_LO)
     bool swap = true; int it = 0;
     // Limit cycles of the bracket update, cut short exactly.  A Newton step from `lo` that overshoots is accepted as the new
     // `lo` although its derivative is positive; the two ends then keep trading roles and only the iteration cap ends the
@@ -437,23 +445,20 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     // lifetimes).  The loop state is the pair (lo.alpha, hi.alpha) -- every other field is a function of alpha -- so once
     // the pair repeats bit for bit with period P the rest is known: (cap - it) mod P more iterations leave exactly the state
     // the cap would have left.  Results are bit-identical to running the cap out (the oracle has the same switch).
-    int cap = m.ls_iterations;
+    const int max_it = opt_ls_iterations;
+    int cap = max_it;
+    // the history lives in lanes (lane k = the pair k + 1 iterations ago): two VGPRs, one ballot per iteration, no scalar
+    // arrays (the kernel is short of SGPRs: sixteen more of them turned into v_writelane / v_readlane spill traffic in this loop)
     constexpr int LS_HIST = 8;
-    int hist_lo[LS_HIST], hist_hi[LS_HIST];
-#pragma unroll
-    for (int k = 0; k < LS_HIST; ++k) { hist_lo[k] = 0; hist_hi[k] = 0; }
-    const bool cut_cycles = m.iterations > 1;
+    float hist_lo = 0.0f, hist_hi = 0.0f;
+    const bool cut_cycles = opt_iterations > 1;
     while (true) {
-      if (cut_cycles && cap == m.ls_iterations) {
-        const int la = uniform_i(__float_as_int(lo.alpha)), ha = uniform_i(__float_as_int(hi.alpha));
-        bool found = false;
-#pragma unroll
-        for (int P = 1; P <= LS_HIST; ++P) {      // smallest period first; hist[P - 1] = the pair P iterations ago
-          if (!found && P <= it && hist_lo[P - 1] == la && hist_hi[P - 1] == ha) { found = true; cap = it + (m.ls_iterations - it) % P; }
-        }
-#pragma unroll
-        for (int k = LS_HIST - 1; k > 0; --k) { hist_lo[k] = hist_lo[k - 1]; hist_hi[k] = hist_hi[k - 1]; }
-        hist_lo[0] = la; hist_hi[0] = ha;
+      if (cut_cycles && cap == max_it) {
+        unsigned long long same = __ballot(hist_lo == lo.alpha && hist_hi == hi.alpha);
+        same &= it >= LS_HIST ? ((1ull << LS_HIST) - 1ull) : ((1ull << it) - 1ull);
+        if (same) { const int P = __builtin_ctzll(same) + 1; cap = it + (max_it - it) % P; }      // smallest period first
+        hist_lo = dpp_mov<0x111>(hist_lo); hist_hi = dpp_mov<0x111>(hist_hi);                       // row_shr:1
+        if (lane == 0) { hist_lo = lo.alpha; hist_hi = hi.alpha; }
       }
       bool ldone = it >= cap;
       ldone |= !swap;
@@ -483,7 +488,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
       ++it;
     }
     ls_total += it;
-    PROF(PS_LS)
+    PROF(PS_L_ITER)
     bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
@@ -493,7 +498,7 @@ __device__ __forceinline__ void solve(const DModel& m, Smem<C>& s, int lane, int
     }
     // A single-iteration solve (opt.iterations == 1, Go2) has no exit test to feed, so when nobody reads qfrc_constraint
     // either (plain Euler) the post-step force / cost / gradient evaluation is dead: stop at the new qacc.
-    if (m.iterations == 1 && !need_force) { ++iter; break; }
+    if (opt_iterations == 1 && !need_force) { ++iter; break; }
     // ---------------- update constraint + gradient ----------------
     rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
     gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
@@ -518,17 +523,17 @@ struct FwdOut { float qacc, qfc, fsmooth; int nefc; SolveStats st; };
 // MJX forward(): position -> collision -> constraint rows -> velocity/actuation -> solve.
 // warm_i is read and replaced by the solver's qacc (qacc_warmstart <- qacc).
 template <class C>
-__device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
+__device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
                         float* dbg PROF_ARG) {
-  kinematics<C>(m, s, lane);
+  kinematics<C>(m, h, s, lane);
   PROF(PS_KIN)
-  com_crb_mass<C>(m, s, lane);
+  com_crb_mass<C>(m, h, s, lane);
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) Mrow[j] = s.M[(lane < C::NV ? lane : 0) * C::LD + j];   // lanes >= NV: row 0, every use is masked
   PROF(PS_COMCRB)
   // velocity stage first: its scratch and the frames die before the Jacobian claims the shared LDS region
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
-  float fs = smooth_forces<C>(m, s, lane, qvel_i, 0.0f);
+  float fs = smooth_forces<C>(m, h, s, lane, qvel_i, 0.0f);
   PROF(PS_SMOOTH)
   // qacc_smooth = M^-1 qfrc_smooth
   float a[C::NV], lt[C::NV];
@@ -537,19 +542,19 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
   const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
   float a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
   PROF(PS_CHOLM)
-  collision<C>(m, s, lane PROF_PASS);
+  collision<C>(m, h, s, lane PROF_PASS);
   PROF(PS_COLL)
   RowRegs rr[C::NCHUNK];
   float bcoef[C::NCHUNK], jqv[C::NCHUNK];
   int nbase;
-  int nefc = make_constraint<C>(m, s, lane, rr, bcoef, nbase PROF_PASS);
+  int nefc = make_constraint<C>(m, h, s, lane, rr, bcoef, nbase PROF_PASS);
   jdot<C>(s, lane, nefc, nbase, rr, qvel_i, jqv);                 // aref = -b (J.qvel) - k imp pos
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) rr[ch].aref -= bcoef[ch] * jqv[ch];
   PROF(PS_ROWS)
   out.fsmooth = fs; out.nefc = nefc;
-  const bool need_force = dbg != nullptr || implicit_integration<C>(m, s, lane);
-  solve<C>(m, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, need_force, out.qacc, out.qfc, out.st PROF_PASS);
+  const bool need_force = dbg != nullptr || implicit_integration<C>(h, s, lane);
+  solve<C>(h, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, need_force, out.qacc, out.qfc, out.st PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
     if (lane == 0) {
@@ -591,9 +596,10 @@ __device__ __forceinline__ void forward(const DModel& m, Smem<C>& s, int lane, f
 
 // integrate one substep after forward(): implicitfast / Euler, then _advance
 template <class C>
-__device__ __forceinline__ void integrate(const DModel& m, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
+__device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
+  const Hot& m = h;
   const int lr = lrec_lane(lane);
-  const int4 rj_ids = lrec<C>(m, LQ_J_IDS, lr), rj_ax = lrec<C>(m, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
+  const int4 rj_ids = lrec<C>(h, LQ_J_IDS, lr), rj_ax = lrec<C>(h, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
   float qacc = f.qacc;
   const bool implicit = implicit_integration<C>(m, s, lane);
   if (implicit) {

@@ -18,7 +18,8 @@ NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "
          "solver_init", "hessian: solve only", "linesearch: p0, lo, iterations", "update_constraint", "integrate", "epilogue+store",
          "hessian: weights+compaction", "hessian: sparse rows", "hessian: contacts", "hessian: block exchange", "hessian: cholesky",
          "linesearch: setup (jdot, M.v, sums)", "x0 collision: SAT / primitives", "x1 collision: clip slots", "x2 collision: compaction",
-         "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: cost + gauss (rest of update = J^T f)", "x7"]
+         "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: cost + gauss (rest of update = J^T f)", "x7",
+         "ls: prepare (row pieces)", "ls: point alpha=0", "ls: first Newton point", "ls: iterations", "-", "init: M.a, J.a, costs of both starts", "init: J^T f, gradient"]
 n = 8192
 if "--go2" in sys.argv:
     from rsr_mjx_amd.envs import go2
@@ -29,6 +30,8 @@ else:
     dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
     env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
     nu, astd = 5, 1.0
+if hasattr(env, "set_schedule"):
+    env.set_schedule(1)          # per-stage counters are written by the unit that ends the env-step: keep the step in one unit
 s = env.reset(prng.split(prng.PRNGKey(0), n))
 dbg = env.enable_debug(True)
 tot = np.zeros(len(NAMES))
