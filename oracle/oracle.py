@@ -147,6 +147,13 @@ class Oracle:
             raise KeyError(name)
         return out[:n].copy()
 
+    def cost(self, qacc) -> float:
+        """The solver's objective at `qacc` on the constraint rows of the last forward() (evaluated in double)."""
+        q = np.ascontiguousarray(qacc, dtype=self.real)
+        self.lib.oracle_debug_cost.restype = C.c_double
+        self.lib.oracle_debug_cost.argtypes = [C.c_void_p, C.c_void_p]
+        return float(self.lib.oracle_debug_cost(self.h, q.ctypes.data))
+
     def set_cull(self, on: bool) -> None:
         self.lib.oracle_set_cull(int(on))
 

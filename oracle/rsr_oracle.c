@@ -265,7 +265,8 @@ static int g_ncon_cap = NCON_MAX;
 /* Line-search stop rule.  0: MJX's (gradient below gtol, no bracket update, or ls_iterations).  1: MJX's plus the HIP kernel's
  * fp32 noise-floor stop for converging solves (iterations > 1): a bracket end also counts as converged when |derivative| is
  * below g_ls_noise * eps * (sum |linear terms| + 2 |alpha| sum |quadratic terms|), the rounding noise of the derivative sum.
- * 2: as 1, and the sign of the derivative is not asked for (|d| below the floor at either end stops the search). */
+ * 2: as 1, and the sign of the derivative is not asked for (|d| below the floor at either end stops the search); like 1 it
+ * leaves single-iteration solves (Go2) on MJX's rule. */
 /* g_ls_cycle: exact shortcut of the search's limit cycles.  The bracket update can enter a cycle (a Newton step from `lo`
  * that overshoots is accepted as the new `lo` although its derivative is positive; the roles of the two ends then keep
  * flipping) that only the iteration cap ends.  The loop state is (lo.alpha, hi.alpha) -- every other field is a function of
@@ -1288,7 +1289,7 @@ static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad)
       if (a > tol_lo) tol_lo = a;
       if (b > tol_hi) tol_hi = b;
     }
-    if (g_ls_rule == 2) {
+    if (g_ls_rule == 2 && noise > 0) {
       done |= (real)fabs((double)lo.deriv0) < tol_lo;
       done |= (real)fabs((double)hi.deriv0) < tol_hi;
     } else {
@@ -1347,6 +1348,7 @@ static void solve(const omodel *m, odata *d) {
   sctx_init(m, d, &c, q0, 1);
   real scale = 1 / (m->meaninertia * (real)(nv > 1 ? nv : 1));
   int iter = 0;
+  if (getenv("RSR_SOLVER_TRACE")) fprintf(stderr, "   oracle start cost_warm %.9g cost_smooth %.9g cost %.9g\n", (double)cost_warm, (double)cost_smooth, (double)c.cost);
   while (1) {
     if (m->iterations != 1) {
       real gn = 0;
@@ -1359,6 +1361,7 @@ static void solve(const omodel *m, odata *d) {
     } else if (iter >= 1) break;
     linesearch(m, d, &c, jv, quad);
     update_constraint(m, d, &c);
+    if (getenv("RSR_SOLVER_TRACE")) fprintf(stderr, "   oracle iter %d cost %.9g ls_total %d\n", iter, (double)c.cost, d->ls_total);
     update_gradient(m, d, &c);
     for (int i = 0; i < nv; i++) c.search[i] = -c.Mgrad[i];
     iter++;
@@ -2357,6 +2360,30 @@ int oracle_debug_get(const omodel *m, const char *name, double *out, int cap) {
   if (!p) return -1;
   for (int i = 0; i < n && i < cap; i++) out[i] = (double)p[i];
   return n;
+}
+/* The solver's objective at a given qacc, on the constraint rows of the last oracle_debug_forward: the Gauss term
+ * 1/2 (M a - f0).(a - a0) plus the row costs.  Lets a test ask how good a minimiser another implementation's
+ * qacc is (in the fp64 build: to fp64 resolution), independently of the path its solver took. */
+double oracle_debug_cost(const omodel *m, const real *qacc) {
+  const odata *d = g_dbg; if (!d) return -1.0;
+  int nv = m->nv, ne = d->ne, nenf = d->ne + d->nf;
+  double cost = 0;
+  for (int r = 0; r < d->nefc; r++) {
+    double x = -(double)d->efc_aref[r], D = d->efc_D[r];
+    for (int i = 0; i < nv; i++) x += (double)d->efc_J[r * nv + i] * (double)qacc[i];
+    if (r < ne) cost += 0.5 * D * x * x;
+    else if (r < nenf) {
+      double fl = d->efc_floss[r], rf = (double)d->efc_R[r] * fl;
+      if (x <= -rf) cost += fl * (-0.5 * rf - x); else if (x >= rf) cost += fl * (-0.5 * rf + x); else cost += 0.5 * D * x * x;
+    } else if (x < 0) cost += 0.5 * D * x * x;
+  }
+  double gauss = 0;
+  for (int i = 0; i < nv; i++) {
+    double Ma = 0;
+    for (int j = 0; j < nv; j++) Ma += (double)d->M[i * nv + j] * (double)qacc[j];
+    gauss += (Ma - (double)d->qfrc_smooth[i]) * ((double)qacc[i] - (double)d->qacc_smooth[i]);
+  }
+  return cost + 0.5 * gauss;
 }
 int oracle_real_size(void) { return (int)sizeof(real); }
 

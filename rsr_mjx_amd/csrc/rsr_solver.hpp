@@ -329,7 +329,7 @@ __device__ __forceinline__ bool implicit_integration(const Hot& m, const Smem<C>
 template <class C>
 __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
                       const float (&Mrow)[C::NV], float fs, float a0, float warm, bool need_force, float& qacc_out, float& qfc_out,
-                      SolveStats& st PROF_ARG) {
+                      SolveStats& st, float* dbg PROF_ARG) {
   const bool dofl = lane < C::NV;
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
   float a[C::NV], lt[C::NV];
@@ -371,6 +371,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   const float opt_tolerance = m.tolerance, opt_ls_tolerance = m.ls_tolerance, opt_meaninertia = m.meaninertia;
   const float scale = 1.0f / (opt_meaninertia * (float)(C::NV > 1 ? C::NV : 1));
   int iter = 0, ls_total = 0;
+  if (dbg && lane == 0) { dbg[7400] = cost_s; dbg[7401] = cost_w; dbg[7402] = cost; }      // parity dump: the solver's trajectory
   float dinv = 0.0f, hw_fact[C::NCHUNK];
   bool have_factor = false;
 #pragma unroll
@@ -506,6 +507,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     wave_sum3(rc, gauss, unused);
     gauss *= 0.5f;
     prev_cost = cost; cost = rc + gauss;
+    if (dbg && lane == 0 && iter < 16) { dbg[7410 + 4 * iter] = cost; dbg[7411 + 4 * iter] = improved ? alpha : 0.0f; dbg[7412 + 4 * iter] = (float)it; dbg[7413 + 4 * iter] = p0.d0; }
     PROF(PS_X6)
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
@@ -554,7 +556,7 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   PROF(PS_ROWS)
   out.fsmooth = fs; out.nefc = nefc;
   const bool need_force = dbg != nullptr || implicit_integration<C>(h, s, lane);
-  solve<C>(h, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, need_force, out.qacc, out.qfc, out.st PROF_PASS);
+  solve<C>(h, s, lane, nefc, nbase, rr, Mrow, fs, a0, warm, need_force, out.qacc, out.qfc, out.st, dbg PROF_PASS);
   warm = out.qacc;
   if (dbg) {   // parity dump (layout: rsr_mjx_amd/_debug_layout in the Python binding)
     if (lane == 0) {

@@ -1,0 +1,63 @@
+"""Per-field parity envelopes of the HIP stepper against the fp32 CPU oracle (tests/golden/parity_envelopes.json).
+
+The envelopes derive from what was measured on an MI355X over 2048 envs x 3 rollout depths per workload
+(tools/gpu_parity_stats.py -> tools/make_parity_envelopes.py; the JSON keeps the measured values and the hash of the kernel
+sources they were measured on).  err = |hip - oracle| / max(1, |oracle|_inf of that env's field), per env.  For every
+(workload, phase, field), with max = max(1e-5, 5 x the measured maximum):   99.9 % of the envs within max (samples of
+>= 1000 envs), none beyond 30 x max,   quantile(err, 0.99) <= p99 (samples of >= 1000 envs),   and at most 1 % of the envs above
+1e-5 where the measurement found none (obs, reward, xpos ... on the Airbot envs).
+Phases: "reset" = the env-step straight after reset, "rollout" = any later step.
+
+What the numbers say (north_star: 1e-5 relative fp32):
+  * everything the learner consumes on the Airbot envs in a rollout -- obs, reward, metrics, xpos, site_xpos, info -- is
+    within 1e-5 on EVERY measured env (cube obs max 4e-6, T-shape 9e-7);
+  * qvel / qacc_warmstart are documented deviations: acceleration-level quantities of an ill-conditioned solve (joint
+    inertia 5e-5, |qacc| ~ 1e3..1e4): p99 1e-4, max 5e-3 against the fp32 oracle, which is itself 10-100x farther from
+    its own fp64 build (column f32_vs_f64_max);
+  * T-shape straight after reset: the reference's reset pose has the T block 6-12 mm inside the table, the solver's cost
+    is ~4e4 with row terms up to 1e8 and its minimum is flat at fp32 resolution, so any two fp32 solvers (and fp32 vs
+    fp64) land up to 1e-4 relative apart in qacc (tools/gpu_tshape_reset_diag.py); test_tshape_reset_solver_quality pins the
+    kernel's answer by its optimality gap instead;
+  * Go2: one Newton iteration / five line-search iterations is an unconverged solve by design; velocities carry that noise
+    (obs p99 5e-5); rough terrain adds true discontinuities where a foot is equidistant from two facets."""
+import json
+import os
+
+import numpy as np
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_envelopes.json")
+ENV = json.load(open(_PATH))
+
+
+def scaled_err(a, b):
+    n = a.shape[0]
+    a, b = np.asarray(a).reshape(n, -1).astype(np.float64), np.asarray(b).reshape(n, -1).astype(np.float64)
+    return (np.abs(a - b) / np.maximum(1.0, np.abs(b).max(axis=1, keepdims=True))).max(axis=1)
+
+
+def bound(kind, phase, field, what="max"):
+    return ENV[kind][phase][field][what]
+
+
+def check(kind, phase, field, got, want, tag="", quantiles=True):
+    """Asserts the envelope of (kind, phase, field) on the per-env scaled error of `got` against `want`; returns the errors.
+    Fields without an envelope are values the step only passes through (targets, constants): exact to 1e-6.  The 99 % quantile
+    is asked for on samples of >= 1000 envs (it is too noisy below); the share of envs above 1e-5 only where the measurement
+    found essentially none (<= 0.2 %): there it is the north_star's own bar, elsewhere 1e-5 sits inside the bulk of the
+    distribution and the share says nothing the quantile does not."""
+    err = scaled_err(got, want)
+    assert np.isfinite(err).all(), (tag, kind, phase, field, "non-finite")
+    if field not in ENV[kind][phase]:
+        assert err.max() <= 1e-6, (tag, kind, phase, field, "pass-through field", float(err.max()))
+        return err
+    e = ENV[kind][phase][field]
+    # the tail is heavy (ill-conditioned solves, contact-mode switches: one env in ~3000 env-steps lands 20-30 x beyond the
+    # measured maximum of a 6000-sample run): one env in a thousand may pass the bound, none may pass 30 x it
+    assert err.max() <= 30.0 * e["max"], (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)))
+    if len(err) >= 1000:
+        assert np.quantile(err, 0.999) <= e["max"], (tag, kind, phase, field, "p99.9", float(np.quantile(err, 0.999)), e["max"])
+    if quantiles and len(err) >= 1000:
+        assert np.quantile(err, 0.99) <= e["p99"], (tag, kind, phase, field, "p99", float(np.quantile(err, 0.99)), e["p99"])
+    if quantiles and len(err) >= 200 and e["measured"]["frac"] <= 0.002:
+        assert np.mean(err > 1e-5) <= 0.01, (tag, kind, phase, field, "share above 1e-5", float(np.mean(err > 1e-5)))
+    return err

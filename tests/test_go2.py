@@ -3,6 +3,7 @@ functions of recorded state, restated in numpy from reference go2/joystick.py; p
 import numpy as np
 import pytest
 
+import parity_envelopes as PE
 from conftest import make_go2_blob
 from rsr_mjx_amd import mjcf, prng
 from rsr_mjx_amd.envs import config as cfg
@@ -340,6 +341,7 @@ def test_go2_hip_parity(oracle_mod, task, randomize, kicks):
               "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
               "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs", "priv_obs", "first_priv_obs"]
     serr = lambda a, b: (np.abs(a.astype(np.float64) - b).reshape(n, -1) / np.maximum(1.0, np.abs(b.astype(np.float64)).reshape(n, -1).max(1, keepdims=True))).max(1)
+    hatch_count = 0
     rng = np.random.default_rng(11)
     for depth in (0, 5, 40):
         for _ in range(depth):
@@ -360,25 +362,31 @@ def test_go2_hip_parity(oracle_mod, task, randomize, kicks):
             np.testing.assert_allclose(get("info_go2")[:, 128:137], st["info_go2"][:, 128:137], rtol=1e-6, atol=1e-6)
             np.testing.assert_allclose(get("info_go2")[:, 139:142], st["info_go2"][:, 139:142], rtol=1e-5, atol=1e-4)
             assert depth == 0 or np.abs(st["info_go2"][:, 139:142]).max() > 1.0 or depth < 40
-        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel", "priv_obs"):
-            eg, ec = serr(get(k), st[k]), serr(st[k], st64[k])
-            # privileged_state carries the accelerometer: an acceleration-level reading (qacc of the one-iteration solve),
-            # one derivative noisier than the velocities the other fields hold
-            thr = 3e-5 if k == "priv_obs" else 1e-5
-            allowed = max(1, int(0.01 * n), int(2.0 * np.sum(ec > thr)))
-            assert np.sum(eg > thr) <= allowed, (depth, k, int(np.sum(eg > thr)), allowed)
-            bound = 1e-4 + 3.0 * ec.max()
-            for w in np.nonzero(eg > bound)[0]:
-                # A larger deviation is accepted only where the dynamics themselves are discontinuous at this state (on the
-                # height field: a foot equidistant from two facets, so the single closest-point contact flips its normal):
-                # the f32 oracle, restarted from the same state moved by 1e-6 or less, must move by a comparable amount.
+        kind, phase = ("go2rough" if task == "Rough" else "go2"), ("reset" if depth == 0 else "rollout")
+        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel", "qacc_warmstart", "priv_obs"):
+            eg = serr(get(k), st[k])
+            env_k = PE.ENV[kind][phase][k]
+            assert np.quantile(eg, 0.98) <= env_k["p99"], (task, depth, k, "p98 of 512 envs against the p99 bound", float(np.quantile(eg, 0.98)), env_k["p99"])
+            # Flat terrain: the measured envelope bounds every env.  On the height field a larger deviation is accepted only
+            # where the dynamics themselves are discontinuous at this state (a foot equidistant from two facets, so the
+            # single closest-point contact flips its normal): the f32 oracle, restarted from the same state moved by 1e-6
+            # or less, must then move by a comparable amount.  The envs that take this way out are counted and bounded.
+            hatch_from = 10.0 * env_k["p99"]                       # rough terrain: anything 10 x beyond the p99 bound has to be explained
+            over = np.nonzero(eg > (env_k["max"] if task != "Rough" else hatch_from))[0]
+            assert task == "Rough" or len(over) == 0, (task, depth, k, "max", float(eg.max()), env_k["max"])
+            hatch_count += len(over)
+            for w in over:
                 sens = 0.0
                 for eps in (1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6):
                     sp = {kk: (v.copy() if v is not None else None) for kk, v in before.items()}
                     sp["qpos"][:, 2] += f32(eps)
                     orc.step(sp, a)
                     sens = max(sens, float(serr(sp[k], st[k])[w]))
-                assert task == "Rough" and eg[w] <= 3.0 * sens + 1e-4, (depth, k, int(w), float(eg[w]), sens, float(ec.max()))
+                assert eg[w] <= 3.0 * sens + 1e-4, (depth, k, int(w), float(eg[w]), sens)
+    # discontinuous states are rare: at most 1 % of the (env, field, depth) samples of the rough-terrain case take the way out
+    assert hatch_count <= 0.01 * n * 9 * 3, hatch_count
+    if task == "Rough":
+        print(f"rough-terrain discontinuity hatch taken by {hatch_count} (env, field) samples of {n * 9 * 3}")
     assert set(state.info) >= {"command", "last_act", "feet_air_time", "action_buffer", "gyro_buffer", "rng", "steps", "truncation"}
     assert state.info["action_buffer"].shape == (n, 4, 12) and len(state.metrics) == 22
 
@@ -415,3 +423,68 @@ def test_accelerometer_is_site_acceleration_minus_gravity(go2_model, oracle_mod)
     q = home.copy(); q[2] = 1.0
     orc.forward(q, np.zeros(18), q[7:])
     assert np.abs(orc.get("accelerometer")).max() < 1.0
+
+
+@pytest.mark.gpu
+def test_go2_truncation_and_autoreset_on_device(oracle_mod):
+    """a16: Go2 under Episode + AutoReset (reference _src/wrapper.py:117-138) across `done`: episode_length = 5 and falls forced
+    on a third of the envs (trunk upside down: up[2] < 0).  HIP and oracle are stepped together, teacher-forced, over two
+    truncation boundaries; done / steps / truncation and the info timers are exact, obs / privileged obs and the restored
+    pipeline block within 1e-5, the info block (never reset by AutoReset) within its envelope."""
+    import torch
+    from rsr_mjx_amd.envs import go2
+    n, L = 96, 5
+    jenv = go2.load("Go2JoystickFlatTerrain")
+    env = go2.wrap_for_brax_training(jenv, n, episode_length=L)
+    orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(41), n)
+    st = orc.new_state(n); orc.reset(st, keys)
+    state = env.reset(keys)
+    torch.cuda.synchronize()
+    gname = {"priv_obs": "privileged_obs", "first_priv_obs": "first_privileged_obs"}
+    get = lambda k: env.view(gname.get(k, k)).cpu().numpy().reshape(st[k].shape)
+    fields = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs", "reward", "done", "metrics", "info_go2",
+              "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
+              "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs", "priv_obs", "first_priv_obs"]
+    serr = lambda a, b: (np.abs(a.astype(np.float64) - b).reshape(n, -1) / np.maximum(1.0, np.abs(b.astype(np.float64)).reshape(n, -1).max(1, keepdims=True))).max(1)
+    rng = np.random.default_rng(41)
+    first_obs, first_priv, first_qpos = st["first_obs"].copy(), st["first_priv_obs"].copy(), st["first_qpos"].copy()
+    saw_fall = saw_trunc = 0
+    for t in range(1, 2 * L + 3):
+        if t in (2, 8):                 # flip a third of the trunks upside down: the env's own termination (joystick.py: up[2] < 0)
+            st["qpos"][::3, 3:7] = np.array([0.0, 1.0, 0.0, 0.0], dtype=f32)
+        for k in fields:
+            env.view(gname.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        a = np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
+        orc.step(st, a)
+        state = env.step(state, a)
+        torch.cuda.synchronize()
+        for k in ("done", "info_steps", "info_truncation", "info_episode_done", "ctrl", "time"):
+            np.testing.assert_array_equal(get(k), st[k], err_msg=f"{k} at step {t}")
+        np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
+        gi, oi = get("info_go2"), st["info_go2"]
+        np.testing.assert_array_equal(gi[:, :4], oi[:, :4])                                   # command + its timer: PRNG only
+        np.testing.assert_array_equal(gi[:, G["STEPS_PERT"]:G["PERT_MAG"] + 1], oi[:, G["STEPS_PERT"]:G["PERT_MAG"] + 1])
+        np.testing.assert_array_equal(gi[:, G["LAST_ACT"]:G["AIR"]], oi[:, G["LAST_ACT"]:G["AIR"]])     # last / last-last actions
+        assert np.mean(np.abs(gi[:, G["AIR"]:G["ACT_BUF"]] - oi[:, G["AIR"]:G["ACT_BUF"]]).max(axis=1) <= 1e-6) >= 0.95    # feet timers, swing peak
+        assert np.quantile(serr(gi[:, :137], oi[:, :137]), 0.95) <= PE.bound("go2", "rollout", "obs")
+        done = st["done"] != 0
+        for k in ("obs", "priv_obs", "qpos", "qvel", "xpos", "site_xpos", "qacc_warmstart"):
+            e = serr(get(k), st[k])
+            assert e[done].max(initial=0.0) <= 1e-5, (t, k, "restored block", float(e[done].max(initial=0.0)))
+            # envs that play on: the physics envelope for 95 % of them; the rest are feet touching down in these first steps after
+            # reset (a contact that one side has and the other not yet is an O(1e-2) velocity change in a one-iteration solve)
+            lim = max(PE.bound("go2", "reset", k), PE.bound("go2", "rollout", k))
+            if (~done).any():
+                assert np.quantile(e[~done], 0.95) <= lim, (t, k, float(np.quantile(e[~done], 0.95)), lim)
+                assert k in ("qvel", "qacc_warmstart") or e[~done].max() <= 0.05, (t, k, float(e[~done].max()))
+        assert serr(get("info_episode_metrics"), st["info_episode_metrics"]).max() <= 1e-4
+        if done.any():
+            # AutoReset: the cached first state replaces pipeline state and observations, bit for bit
+            np.testing.assert_array_equal(get("obs")[done], first_obs[done])
+            np.testing.assert_array_equal(get("priv_obs")[done], first_priv[done])
+            np.testing.assert_array_equal(get("qpos")[done], first_qpos[done])
+            assert not get("info_go2")[done][:, 139:142].any()                               # xfrc_applied belongs to `data`: zeroed
+        saw_fall += int((done & (st["info_truncation"] == 0)).sum())
+        saw_trunc += int((st["info_truncation"] != 0).sum())
+    assert saw_fall >= n // 3 and saw_trunc >= n, (saw_fall, saw_trunc)

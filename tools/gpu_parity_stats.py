@@ -22,10 +22,10 @@ def serr(a, b):
 
 
 def make(kind, n):
-    if kind in ("cube", "tshape"):
-        from rsr_mjx_amd.envs.airbot import AirbotPlayBase, AirbotTShape, domain_randomize
-        envdef = AirbotTShape() if kind == "tshape" else AirbotPlayBase()
-        dr = None if kind == "tshape" else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(5), n))
+    if kind in ("cube", "tshape", "sf"):
+        from rsr_mjx_amd.envs.airbot import AirbotPlayBase, AirbotPlaySF, AirbotTShape, domain_randomize
+        envdef = AirbotTShape() if kind == "tshape" else (AirbotPlaySF() if kind == "sf" else AirbotPlayBase())
+        dr = None if kind != "cube" else domain_randomize(envdef.sys, prng.split(prng.PRNGKey(5), n))
         env = envdef.batched(n, episode_length=1200, auto_reset=True, randomization=dr)
         odr, nu, astd, depths = dr, 5, 1.0, (0, 7, 53)
         fields = ["qpos", "qvel", "qacc_warmstart", "xpos", "site_xpos", "obs", "reward", "metrics", "ctrl"]
@@ -46,7 +46,7 @@ def main():
     args = sys.argv[1:]
     n = int(args[args.index("--n") + 1]) if "--n" in args else 2048
     out_json = args[args.index("--json") + 1] if "--json" in args else None
-    kinds = [a for a in args if a in ("cube", "tshape", "go2", "go2rough")] or ["cube", "tshape", "go2", "go2rough"]
+    kinds = [a for a in args if a in ("cube", "sf", "tshape", "go2", "go2rough")] or ["cube", "sf", "tshape", "go2", "go2rough"]
     result = {}
     for kind in kinds:
         env, odr, nu, astd, depths, fields = make(kind, n)

@@ -23,14 +23,15 @@ st = o32.new_state(n)
 o32.set_ls_rule(0)
 o32.reset(st, prng.split(prng.PRNGKey(0), n))
 rng = np.random.default_rng(0)
-samples = []
+samples = [(st["qpos"].copy(), st["qvel"].copy(), st["ctrl"].copy(), st["qacc_warmstart"].copy())]      # straight after reset
 for t in range(41):
     act = np.clip(rng.normal(size=(n, o32.nu)), -1, 1).astype(np.float32)
     o32.step(st, act)
     if t % 10 == 0:
         samples.append((st["qpos"].copy(), st["qvel"].copy(), st["ctrl"].copy(), st["qacc_warmstart"].copy()))
 variants = [("mjx", 0, 1.0, 0, 0), ("mjx + cycle cut", 0, 1.0, 1, 0), ("floor x1 (kernel r1)", 1, 1.0, 0, 0), ("floor x1 + cycle cut", 1, 1.0, 1, 0),
-            ("floor x1 |d| + cycle", 2, 1.0, 1, 0), ("floor x4 |d| + cycle", 2, 4.0, 1, 0)]
+            ("floor x1 |d| + cycle", 2, 1.0, 1, 0), ("floor x0.3 |d| + cycle", 2, 0.3, 1, 0), ("floor x0.1 |d| + cycle", 2, 0.1, 1, 0),
+            ("floor x0.03 |d| + cycle", 2, 0.03, 1, 0), ("floor x0.01 |d| + cycle", 2, 0.01, 1, 0), ("floor x0.1 signed + cycle", 1, 0.1, 1, 0)]
 truth = []
 for (Q, V, U, W) in samples:
     for e in range(n):
