@@ -1695,9 +1695,9 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
     s->info_steps[e] = steps;
     float prev_done = s->info_episode_done[e];
     float *em = &s->info_episode_metrics[e * (2 + m->nmetrics)];
-    em[0] = (em[0] + reward) * (1.0f - prev_done);
-    em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
-    for (int i = 0; i < m->nmetrics; i++) em[2 + i] = (em[2 + i] + s->metrics[e * m->nmetrics + i]) * (1.0f - prev_done);
+    em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
+    em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
+    for (int i = 0; i < m->nmetrics; i++) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + s->metrics[e * m->nmetrics + i];
     if (over) s->done[e] = 1.0f;
     s->info_episode_done[e] = s->done[e];
   }
@@ -1760,9 +1760,9 @@ static void wrappers_post(const omodel *m, obatch *s, int e, float reward) {
     s->info_steps[e] = steps;
     float prev_done = s->info_episode_done[e];
     float *em = &s->info_episode_metrics[e * (2 + m->nmetrics)];
-    em[0] = (em[0] + reward) * (1.0f - prev_done);
-    em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
-    for (int i = 0; i < m->nmetrics; i++) em[2 + i] = (em[2 + i] + s->metrics[e * m->nmetrics + i]) * (1.0f - prev_done);
+    em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
+    em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
+    for (int i = 0; i < m->nmetrics; i++) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + s->metrics[e * m->nmetrics + i];
     if (over) s->done[e] = 1.0f;
     s->info_episode_done[e] = s->done[e];
   }

@@ -556,11 +556,13 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
       steps += 1.0f;
       bool over = steps >= (float)m.episode_length;
       rec[L.truncation] = over ? 1.0f - done : 0.0f;
+      // brax: metric = (metric + x) * (1 - prev_done).  Written as a select: the same value for finite metrics, and an env whose
+      // simulation went non-finite once (a blow-up) starts its next episode's sums clean instead of carrying NaN * 0 = NaN forever.
       float prev_done = rec[L.episode_done];
       float* em = rec + L.episode_metrics;
-      em[0] = (em[0] + reward) * (1.0f - prev_done);
-      em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
-      for (int i = 0; i < C::NMET; ++i) em[2 + i] = (em[2 + i] + met[i]) * (1.0f - prev_done);
+      em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
+      em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
+      for (int i = 0; i < C::NMET; ++i) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + met[i];
       if (over) done = 1.0f;
       rec[L.episode_done] = done;
     }
@@ -959,9 +961,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
       rec[L.truncation] = over ? 1.0f - done : 0.0f;
       float prev_done = rec[L.episode_done];
       float* em = rec + L.episode_metrics;
-      em[0] = (em[0] + reward) * (1.0f - prev_done);
-      em[1] = (em[1] + 1.0f) * (1.0f - prev_done);
-      for (int i = 0; i < C::NMET; ++i) em[2 + i] = (em[2 + i] + rwl[i]) * (1.0f - prev_done);
+      em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
+      em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
+      for (int i = 0; i < C::NMET; ++i) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + rwl[i];
       if (over) done = 1.0f;
       rec[L.episode_done] = done;
     }
@@ -1090,11 +1092,35 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   if (!blob || !out || nbytes < 32) return fail(RSR_ERR_ARG, "rsr_model_create: null or short blob");
   const int32_t* h = static_cast<const int32_t*>(blob);
   if (std::memcmp(blob, "RSRM", 4) != 0 || h[1] != 1 || (size_t)h[3] > nbytes) return fail(RSR_ERR_ARG, "rsr_model_create: not an RSRM v1 blob");
+  {  // every directory entry must lie inside the blob before anything is read through it (header: magic, version, entry count, bytes)
+    const long long nent = h[2];
+    if (nent < 0 || 16 + (unsigned long long)nent * sizeof(blob_entry) > nbytes) return fail(RSR_ERR_ARG, "rsr_model_create: entry table exceeds the blob");
+    const blob_entry* e = reinterpret_cast<const blob_entry*>(static_cast<const char*>(blob) + 16);
+    for (long long i = 0; i < nent; ++i) {
+      const bool named = std::memchr(e[i].name, 0, sizeof(e[i].name)) != nullptr;
+      if (!named || e[i].count < 0 || e[i].offset < 0 || (e[i].offset & 3) || (unsigned long long)e[i].offset + 4ull * (unsigned long long)e[i].count > nbytes)
+        return fail(RSR_ERR_ARG, "rsr_model_create: blob entry " + std::to_string(i) + " has no name terminator or points outside the blob");
+    }
+  }
   rsr_model* m = new rsr_model();
   m->blob.assign(static_cast<const char*>(blob), static_cast<const char*>(blob) + nbytes);
-  const int* dims = static_cast<const int*>(m->find("dims"));
-  const int* ei = static_cast<const int*>(m->find("env_int"));
-  if (!dims || !ei) { delete m; return fail(RSR_ERR_ARG, "rsr_model_create: blob lacks dims/env_int"); }
+  int ndims = 0, nei = 0;
+  const int* dims = static_cast<const int*>(m->find("dims", &ndims));
+  const int* ei = static_cast<const int*>(m->find("env_int", &nei));
+  if (!dims || !ei || ndims < 9 || nei < 6) { delete m; return fail(RSR_ERR_ARG, "rsr_model_create: blob lacks dims/env_int"); }
+  {  // fields read below or by fill_dmodel without a further check
+    static const char* const need[] = {"counts2", "opt_integrator", "opt_timestep", "opt_gravity", "opt_tolerance", "opt_ls_tolerance", "opt_impratio",
+                                       "stat_meaninertia", "opt_iterations", "opt_ls_iterations", "opt_disable_eulerdamp", "opt_disable_refsafe",
+                                       "pair_condim", "pair_kind", "pair_geom1", "pair_geom2", "geom_size", "eq_active0", "lane_rec"};
+    for (const char* f : need) {
+      int cnt = 0;
+      if (!m->find(f, &cnt) || (cnt < 1 && std::strcmp(f, "pair_condim") && std::strcmp(f, "pair_kind") && std::strcmp(f, "pair_geom1") && std::strcmp(f, "pair_geom2") && std::strcmp(f, "eq_active0"))) {
+        delete m; return fail(RSR_ERR_ARG, std::string("rsr_model_create: blob lacks field ") + f);
+      }
+    }
+    int nc2 = 0, ng = 0; m->find("counts2", &nc2); m->find("opt_gravity", &ng);
+    if (nc2 < 4 || ng < 3) { delete m; return fail(RSR_ERR_ARG, "rsr_model_create: counts2 / opt_gravity too short"); }
+  }
   rsr_dims& d = m->dims;
   d.nq = dims[0]; d.nv = dims[1]; d.nu = dims[2]; d.nbody = dims[3]; d.njnt = dims[4]; d.ngeom = dims[5];
   d.nsite = dims[6]; d.neq = dims[7]; d.npair = dims[8];
@@ -1155,7 +1181,9 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
         const float cell = std::fmin(2.0f * hs[0] / (float)(hc[0] - 1), 2.0f * hs[1] / (float)(hr[0] - 1));
         const int* g2 = static_cast<const int*>(m->find("pair_geom2"));
         const float* gs = static_cast<const float*>(m->find("geom_size"));
-        for (int i = 0; i < npk; ++i) if (pk[i] == rsr::PAIR_HFIELD_SPHERE && 2.0f * gs[3 * g2[i]] > cell) okh = false;
+        int ng2 = 0, ngs = 0; m->find("pair_geom2", &ng2); m->find("geom_size", &ngs);
+        for (int i = 0; i < npk; ++i)
+          if (pk[i] == rsr::PAIR_HFIELD_SPHERE && (i >= ng2 || g2[i] < 0 || 3 * g2[i] + 2 >= ngs || 2.0f * gs[3 * g2[i]] > cell)) okh = false;
       }
       if (!okh) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: height-field pairs need the Go2 kernels, exactly one height field of at least 3x3 samples, and spheres no wider than a grid cell"); }
     }
@@ -1241,13 +1269,22 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     (void)hipMemset(b->state, 0, bytes);
   }
   if (hipMalloc(&b->dblob, m->blob.size()) != hipSuccess) { if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(model)"); }
-  HIPCHK(hipMemcpy(b->dblob, m->blob.data(), m->blob.size(), hipMemcpyHostToDevice));
+  auto release = [&]() {            // every failure path below frees what has been allocated so far
+    if (b->dmodel) (void)hipFree(b->dmodel);
+    if (b->sched) (void)hipFree(b->sched);
+    if (b->dblob) (void)hipFree(b->dblob);
+    if (b->owns_state && b->state) (void)hipFree(b->state);
+    delete b;
+  };
+  b->dmodel = nullptr; b->sched = nullptr;
+  { hipError_t ce = hipMemcpy(b->dblob, m->blob.data(), m->blob.size(), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { release(); return fail(RSR_ERR_HIP, std::string("rsr_batch_create: hipMemcpy(model): ") + hipGetErrorString(ce)); } }
   int rc = fill_dmodel(m, b->dblob, b->dm);
-  if (rc) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return rc; }
-  b->sched = nullptr; b->launch_id = 0; b->units = 1; b->step_grid = 0;
+  if (rc) { release(); return rc; }
+  b->launch_id = 0; b->units = 1; b->step_grid = 0;
   if (m->dims.env_kind != rsr::ENV_GO2) {
     const size_t sb = (2 + (size_t)num_envs) * sizeof(int);
-    if (hipMalloc(&b->sched, sb) != hipSuccess) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
+    if (hipMalloc(&b->sched, sb) != hipSuccess) { b->sched = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
     (void)hipMemset(b->sched, 0, sb);
     // resident waves of the step kernel on this device: the grid of the persistent launch
     int per_cu = 0; hipDeviceProp_t prop;
@@ -1261,9 +1298,9 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     if (b->units < 1) b->units = 1;
     if (b->units > m->dims.n_frames) b->units = m->dims.n_frames;
   }
-  b->dmodel = nullptr;
-  if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { (void)hipFree(b->dblob); if (b->owns_state) (void)hipFree(b->state); delete b; return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
-  HIPCHK(hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice));
+  if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { b->dmodel = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
+  { hipError_t ce = hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { release(); return fail(RSR_ERR_HIP, std::string("rsr_batch_create: hipMemcpy(dmodel): ") + hipGetErrorString(ce)); } }
   *out = b;
   return RSR_OK;
 }

@@ -12,16 +12,26 @@ def _module_arrays(prefix: str, module) -> Dict[str, np.ndarray]:
     return {f"{prefix}/{k}": v.detach().cpu().numpy() for k, v in module.state_dict().items()}
 
 
+_STATS = ("count", "mean", "summed_variance", "std")
+
+
+def _stats_arrays(prefix: str, rs) -> Dict[str, np.ndarray]:
+    return {f"{prefix}/{name}": getattr(rs, name).cpu().numpy() for name in _STATS}
+
+
 def save_params(path: str, params: Tuple[Any, ...]) -> None:
     """`params` as returned by ppo_train.train: (normalizer or None, PPONetworks), or by sac_train.train:
-    (normalizer or None, policy_net, TwinQ)."""
+    (normalizer or None, policy_net, TwinQ).  The reference checkpoints the whole normalizer pytree, i.e. the statistics of
+    every observation key: the critic's own normaliser (PPONetworks.value_normalizer, present when the critic reads another
+    observation key such as Go2's privileged_state) is saved under value_normalizer/."""
     out: Dict[str, np.ndarray] = {}
     normalizer = params[0]
     if normalizer is not None:
-        out.update({"normalizer/count": normalizer.count.cpu().numpy(), "normalizer/mean": normalizer.mean.cpu().numpy(),
-                    "normalizer/summed_variance": normalizer.summed_variance.cpu().numpy(), "normalizer/std": normalizer.std.cpu().numpy()})
+        out.update(_stats_arrays("normalizer", normalizer))
     if len(params) == 2:                                   # PPO
         out.update(_module_arrays("policy", params[1].policy)); out.update(_module_arrays("value", params[1].value))
+        if getattr(params[1], "value_normalizer", None) is not None:
+            out.update(_stats_arrays("value_normalizer", params[1].value_normalizer))
     else:                                                  # SAC
         out.update(_module_arrays("policy", params[1])); out.update(_module_arrays("q1", params[2].q1)); out.update(_module_arrays("q2", params[2].q2))
     np.savez(path, **out)
@@ -34,11 +44,18 @@ def load_params(path: str, params: Tuple[Any, ...]) -> None:
     def into(prefix, module):
         sd = {k[len(prefix) + 1:]: torch.as_tensor(z[k]) for k in z.files if k.startswith(prefix + "/")}
         module.load_state_dict(sd)
+    def stats(prefix, rs):
+        for name in _STATS:
+            getattr(rs, name).copy_(torch.as_tensor(z[f"{prefix}/{name}"]))
     normalizer = params[0]
     if normalizer is not None:
-        for name in ("count", "mean", "summed_variance", "std"):
-            getattr(normalizer, name).copy_(torch.as_tensor(z[f"normalizer/{name}"]))
+        stats("normalizer", normalizer)
     if len(params) == 2:
         into("policy", params[1].policy); into("value", params[1].value)
+        vn = getattr(params[1], "value_normalizer", None)
+        if vn is not None:
+            if "value_normalizer/count" not in z.files:
+                raise KeyError("checkpoint has no value_normalizer/ statistics but the critic normalises its own observation key")
+            stats("value_normalizer", vn)
     else:
         into("policy", params[1]); into("q1", params[2].q1); into("q2", params[2].q2)

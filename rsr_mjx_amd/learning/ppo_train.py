@@ -72,6 +72,7 @@ class PPONetworks:
         self.policy = make_mlp([observation_size, *policy_hidden_layer_sizes, 2 * action_size], device)
         self.value = make_mlp([observation_size, *value_hidden_layer_sizes, 1], device)
         self.action_size = action_size
+        self.value_normalizer = None      # RunningStatistics of the critic's own observation key, when it has one (train())
 
     def parameters(self):
         return list(self.policy.parameters()) + list(self.value.parameters())
@@ -199,6 +200,7 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
         networks.value = make_mlp([vobs_size, *value_hidden_layer_sizes, 1], device)
     normalizer = RunningStatistics(obs_size, device) if normalize_observations else None
     vnormalizer = RunningStatistics(vobs_size, device) if (normalize_observations and value_obs_key) else None
+    networks.value_normalizer = vnormalizer          # travels with the networks: returned, handed to policy_params_fn, checkpointed
     params_list = networks.parameters()
     if use_graph is None:
         use_graph = device.type == "cuda"

@@ -45,12 +45,8 @@ def evaluate_kde(data, grid, bandwidth: float = 0.1):
 
 
 def kl_divergence(p, q):
-    return (p * torch_log((p + 1e-10) / (q + 1e-10))).sum()
-
-
-def torch_log(x):
     import torch
-    return torch.log(x)
+    return (p * torch.log((p + 1e-10) / (q + 1e-10))).sum()
 
 
 def wasserstein_distance(p, q):
@@ -58,53 +54,55 @@ def wasserstein_distance(p, q):
     return (torch.cumsum(p, 0) - torch.cumsum(q, 0)).abs().sum()
 
 
+def _same_table(named) -> None:
+    """All tensors are [rows, width] tables of one common shape (the three transition sets share rows and columns)."""
+    shapes = {name: tuple(t.shape) for name, t in named.items()}
+    first = next(iter(shapes.values()))
+    if len(first) != 2 or any(sh != first for sh in shapes.values()):
+        raise ValueError(f"RSR transition tables must be 2-D and of one shape; got {shapes}")
+
+
 def build_rsr_data(real_data, previous_sim_data, current_sim_data, *, num_samples: int = 10, min_value: float = -3.0,
                    max_value: float = 3.0, bandwidth: float = 0.1, seed: int = 0) -> RSRData:
-    if real_data.dim() != 2:
-        raise ValueError(f"real_data must be rank 2, got shape {tuple(real_data.shape)}")
-    if previous_sim_data.shape != real_data.shape:
-        raise ValueError(f"previous_sim_data must match real_data: {tuple(previous_sim_data.shape)} != {tuple(real_data.shape)}")
-    if current_sim_data.shape != real_data.shape:
-        raise ValueError(f"current_sim_data must match real_data: {tuple(current_sim_data.shape)} != {tuple(real_data.shape)}")
-    if num_samples <= 0:
-        raise ValueError(f"num_samples must be positive, got {num_samples}")
-    if bandwidth <= 0:
-        raise ValueError(f"bandwidth must be positive, got {bandwidth}")
+    """The fixed part of the loss: KL(real || previous sim) on the grid, and the current sim's density / data as the reference."""
+    _same_table({"real_data": real_data, "previous_sim_data": previous_sim_data, "current_sim_data": current_sim_data})
+    if not (num_samples > 0 and bandwidth > 0):
+        raise ValueError(f"need a positive grid size and bandwidth; got num_samples={num_samples}, bandwidth={bandwidth}")
     grid = make_grid(num_samples, real_data.shape[-1], min_value, max_value, seed, device=real_data.device, dtype=real_data.dtype)
-    real_density = evaluate_kde(real_data, grid, bandwidth)
-    previous_sim_density = evaluate_kde(previous_sim_data, grid, bandwidth)
-    reference_density = evaluate_kde(current_sim_data, grid, bandwidth)
-    return RSRData(divergence=kl_divergence(real_density, previous_sim_density), reference_density=reference_density,
+    density = {name: evaluate_kde(table, grid, bandwidth)
+               for name, table in (("real", real_data), ("previous", previous_sim_data), ("current", current_sim_data))}
+    return RSRData(divergence=kl_divergence(density["real"], density["previous"]), reference_density=density["current"],
                    reference_data=current_sim_data, grid=grid, bandwidth=bandwidth)
 
 
 def _as_rsr_data(past_data: Any) -> RSRData:
-    """the RSRData format and the legacy 3-tuple (KLD, density, reference_data) (rsr_loss.py:92-119)."""
+    """RSRData, its five fields as a sequence, or the older three-field form (divergence, density, data) whose grid and bandwidth
+    were implicit: the default grid of the density's length over [-3, 3] with seed 0, bandwidth 0.1 (rsr_loss.py:92-119)."""
     if isinstance(past_data, RSRData):
         return past_data
-    if not isinstance(past_data, (tuple, list)):
-        raise TypeError("past_data must be RSRData or a tuple/list")
-    if len(past_data) == 5:
-        return RSRData(*past_data)
-    if len(past_data) != 3:
-        raise ValueError("legacy past_data must contain (KLD, density, reference_data)")
-    divergence, reference_density, reference_data = past_data
-    grid = make_grid(int(reference_density.shape[0]), int(reference_data.shape[-1]), device=reference_data.device, dtype=reference_data.dtype)
-    return RSRData(divergence, reference_density, reference_data, grid, 0.1)
+    fields = tuple(past_data) if isinstance(past_data, (tuple, list)) else None
+    if fields is not None and len(fields) == len(RSRData._fields):
+        return RSRData(*fields)
+    if fields is not None and len(fields) == 3:
+        divergence, density, data = fields
+        grid = make_grid(int(density.shape[0]), int(data.shape[-1]), device=data.device, dtype=data.dtype)
+        return RSRData(divergence, density, data, grid, 0.1)
+    raise TypeError(f"past_data: expected RSRData, its {len(RSRData._fields)} fields, or (divergence, density, data); got {type(past_data).__name__}"
+                    + (f" of length {len(fields)}" if fields is not None else ""))
 
 
 def compute_rsr_loss(observations, policy_actions, next_observations, past_data: Any, *, loss_scale: float = 1.0) -> Tuple[Any, Any]:
-    """(scaled_loss, distribution_distance); any number of leading dims on the three online tensors."""
+    """(scaled_loss, distribution_distance); any number of leading dims on the three online tensors.  The online transitions
+    (s, a, s') join the reference data, the joint density is re-estimated on the grid, and its Wasserstein distance to the
+    reference density, weighted by the fixed real-vs-sim divergence, is the loss (rsr_loss.py:122-175)."""
     import torch
     if past_data is None or loss_scale == 0.0:
         zero = torch.zeros((), dtype=observations.dtype, device=observations.device)
         return zero, zero
     d = _as_rsr_data(past_data)
-    cur = torch.cat([observations.reshape(-1, observations.shape[-1]), policy_actions.reshape(-1, policy_actions.shape[-1]),
-                     next_observations.reshape(-1, next_observations.shape[-1])], dim=-1)
-    if cur.shape[-1] != d.reference_data.shape[-1]:
-        raise ValueError(f"online transition width does not match RSR reference data: {cur.shape[-1]} != {d.reference_data.shape[-1]}")
-    augmented = torch.cat([d.reference_data, cur], dim=0)
-    density = evaluate_kde(augmented, d.grid, d.bandwidth)
+    online = torch.cat([t.reshape(-1, t.shape[-1]) for t in (observations, policy_actions, next_observations)], dim=-1)
+    if online.shape[-1] != d.reference_data.shape[-1]:
+        raise ValueError(f"online transitions are {online.shape[-1]} wide (obs + action + next obs), the RSR reference data {d.reference_data.shape[-1]}")
+    density = evaluate_kde(torch.cat([d.reference_data, online], dim=0), d.grid, d.bandwidth)
     distance = wasserstein_distance(density, d.reference_density)
     return loss_scale * d.divergence * distance, distance

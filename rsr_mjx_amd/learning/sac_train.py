@@ -75,6 +75,29 @@ class ReplayBuffer:
                           {"state_extras": {"truncation": self.truncation[idx]}})
 
 
+def sgd_step(log_alpha, q, target_q, policy_net, qf, tqf, losses, optimizers, transitions, noises, tau: float):
+    """One SAC update in brax 0.12.1's order (sac/train.py sgd_step): the three losses are all taken at the training state as it
+    entered the step -- alpha = exp(alpha_params) before the alpha update, the actor loss against the critic before the critic
+    update -- then the three optimisers step, and the target network tracks the NEW critic.  Returns the three loss tensors."""
+    import torch
+    alpha_loss, critic_loss, actor_loss = losses
+    alpha_opt, q_opt, policy_opt = optimizers
+    alpha = torch.exp(log_alpha).detach()
+    la = alpha_loss(log_alpha, transitions, noises[0])
+    lc = critic_loss(qf, tqf, alpha, transitions, noises[1])
+    lp = actor_loss(qf, alpha, transitions, noises[2])
+    for opt in optimizers:
+        opt.zero_grad(set_to_none=True)
+    la.backward(inputs=[log_alpha])
+    lc.backward(inputs=list(q.parameters()))
+    lp.backward(inputs=list(policy_net.parameters()))
+    alpha_opt.step(); q_opt.step(); policy_opt.step()
+    with torch.no_grad():
+        for tp, p in zip(target_q.parameters(), q.parameters()):
+            tp.mul_(1.0 - tau).add_(p, alpha=tau)
+    return la, lc, lp
+
+
 def train(environment, num_timesteps: int, episode_length: int, past_data: Any = None, action_repeat: int = 1, num_envs: int = 1,
           num_eval_envs: int = 128, learning_rate: float = 1e-4, discounting: float = 0.9, seed: int = 0, batch_size: int = 256,
           num_evals: int = 1, normalize_observations: bool = False, reward_scaling: float = 1.0, tau: float = 0.005,
@@ -168,16 +191,8 @@ def train(environment, num_timesteps: int, episode_length: int, past_data: Any =
             for _u in range(grad_updates_per_step):
                 tr = buffer.sample(batch_size, gen)
                 noise = lambda: torch.randn((batch_size, act_size), generator=gen, device=device)
-                la = alpha_loss(log_alpha, tr, noise())
-                alpha_opt.zero_grad(set_to_none=True); la.backward(); alpha_opt.step()
-                alpha = torch.exp(log_alpha).detach()
-                lc = critic_loss(qf, tqf, alpha, tr, noise())
-                q_opt.zero_grad(set_to_none=True); lc.backward(); q_opt.step()
-                lp = actor_loss(qf, alpha, tr, noise())
-                policy_opt.zero_grad(set_to_none=True); lp.backward(); policy_opt.step()
-                with torch.no_grad():
-                    for tp, p in zip(target_q.parameters(), q.parameters()):
-                        tp.mul_(1.0 - tau).add_(p, alpha=tau)
+                la, lc, lp = sgd_step(log_alpha, q, target_q, policy_net, qf, tqf, (alpha_loss, critic_loss, actor_loss),
+                                      (alpha_opt, q_opt, policy_opt), tr, (noise(), noise(), noise()), tau)
                 agg["alpha_loss"] += float(la.detach()); agg["critic_loss"] += float(lc.detach()); agg["actor_loss"] += float(lp.detach())
             current_step += env_steps_per_actor_step
         if torch.cuda.is_available():

@@ -78,3 +78,35 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "from oracle" not in text and "import oracle" not in text and "liboracle" not in text, fn
                 assert "rsr_oracle.c" not in text, fn
+
+
+def test_malformed_blobs_are_refused(lib, cube_model):
+    """rsr_model_create validates the blob's directory before reading through it: truncated blobs, entries pointing outside
+    the blob, absurd entry counts and missing fields all return RSR_ERR_ARG (-1) with a message, never a crash."""
+    import struct
+    blob = make_blob(cube_model, episode_length=1200, auto_reset=True)
+    h = C.c_void_p()
+    ok = lambda b: lib.rsr_model_create(C.create_string_buffer(bytes(b), len(b)), len(b), C.byref(h))
+    assert ok(blob) == 0
+    lib.rsr_model_destroy(h)
+    nent = struct.unpack_from("<i", blob, 8)[0]
+    assert nent > 50
+    # (1) cut in the middle of the entry table / of the data
+    assert ok(blob[:16 + 56 * 3 + 10]) == -1
+    assert ok(blob[:len(blob) // 2]) == -1
+    # (2) entry count far larger than the blob
+    b = bytearray(blob); struct.pack_into("<i", b, 8, 10 ** 8)
+    assert ok(b) == -1 and b"entry table" in lib.rsr_last_error()
+    # (3) one entry's offset / count pointing past the end
+    for field_off, val in ((48, len(blob)), (44, 10 ** 8), (48, -4)):       # blob_entry: name[40], dtype, count, offset, reserved
+        b = bytearray(blob); struct.pack_into("<i", b, 16 + 56 * 5 + field_off, val)
+        assert ok(b) == -1, (field_off, val)
+    # (4) a required field renamed away
+    b = bytearray(blob)
+    idx = bytes(b).find(b"opt_integrator\0")
+    assert idx > 0
+    b[idx:idx + 3] = b"xxx"
+    assert ok(b) == -1 and b"opt_integrator" in lib.rsr_last_error()
+    # (5) a name without terminator
+    b = bytearray(blob); b[16:16 + 40] = b"a" * 40
+    assert ok(b) == -1

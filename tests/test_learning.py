@@ -388,3 +388,128 @@ def test_checkpoint_roundtrip(tmp_path):
     assert torch.equal(a.value(obs), b.value(obs)) and nb.count.item() == 50
     with pytest.raises(Exception):
         load_params(str(tmp_path / "ckpt.npz"), (nb, PPONetworks(7, 2)))
+
+
+@pytest.mark.gpu
+def test_device_losses_match_the_numpy_restatement():
+    """f2: the learner-side arithmetic AS IT RUNS ON THE GPU (fp32 tensors on cuda:0, GEMM-form KDE) against the independent numpy
+    fp64 restatement of the reference's formulas (oracle/losses_np.py: explicit (M, N, D) differences, reverse-scan GAE) --
+    an oracle, not the same torch code in another precision.  PPO total / policy / value / entropy terms, the RSR term, KDE,
+    KL and Wasserstein."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(13)
+    B, T, Do, A = 48, 16, 23, 5
+    data = _transition(rng, B, T, Do, A)
+    Wp, Wv = rng.normal(size=(Do, 2 * A)) * 0.2, rng.normal(size=(Do,)) * 0.2
+    noise = rng.normal(size=(T, B, A))
+    c = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    d = Transition(c(data.observation), c(data.action), c(data.reward), c(data.discount), c(data.next_observation),
+                   {"state_extras": {k: c(v) for k, v in data.extras["state_extras"].items()},
+                    "policy_extras": {k: c(v) for k, v in data.extras["policy_extras"].items()}})
+    wp, wv = c(Wp), c(Wv)
+    ref = rng.normal(size=(200, Do + A + Do))
+    rd = R.build_rsr_data(c(ref), c(ref * 1.2 + 0.1), c(ref * 0.9), num_samples=10, bandwidth=3.0)
+    total, m = P.compute_ppo_loss(lambda o: o @ wp, lambda o: o @ wv, d, c(noise), past_data=rd, rsr_loss_scale=1.5)
+    # the restatement, fed the same numbers in float64
+    sw = lambda x: np.asarray(x, dtype=np.float64).swapaxes(0, 1)
+    obs, nobs = sw(data.observation), sw(data.next_observation)
+    grid = rd.grid.double().cpu().numpy()
+    dens = {k: O.evaluate_kde(v, grid, 3.0) for k, v in (("real", ref), ("prev", ref * 1.2 + 0.1), ("cur", ref * 0.9))}
+    np.testing.assert_allclose(rd.reference_density.cpu().numpy(), dens["cur"], rtol=2e-4, atol=1e-7)
+    kl = O.kl_divergence(dens["real"], dens["prev"])
+    assert rd.divergence.item() == pytest.approx(kl, rel=2e-3)
+    logits = obs @ Wp
+    loc = np.tanh(np.split(logits, 2, axis=-1)[0])                          # the policy's mode action enters the RSR term
+    rsr, dist = O.compute_rsr_loss(obs, loc, nobs, kl, dens["cur"], ref * 0.9, grid, 3.0, loss_scale=1.5)
+    want = O.ppo_loss(logits, obs @ Wv, nobs[-1] @ Wv, sw(data.reward), sw(data.discount), sw(data.extras["state_extras"]["truncation"]),
+                      sw(data.extras["policy_extras"]["raw_action"]), sw(data.extras["policy_extras"]["log_prob"]), noise, rsr)
+    assert m["sim2real_loss"].item() == pytest.approx(rsr, rel=5e-3, abs=1e-7) and rsr > 0
+    assert m["policy_loss"].item() == pytest.approx(want[1], rel=2e-3, abs=2e-5)
+    assert m["v_loss"].item() == pytest.approx(want[2], rel=2e-4)
+    assert m["entropy_loss"].item() == pytest.approx(want[3], rel=2e-4)
+    assert total.item() == pytest.approx(want[0], rel=1e-3)
+    p, q = rng.dirichlet(np.ones(40)), rng.dirichlet(np.ones(40))
+    assert R.wasserstein_distance(c(p), c(q)).item() == pytest.approx(O.wasserstein_distance(p, q), rel=1e-4)
+    assert R.kl_divergence(c(p), c(q)).item() == pytest.approx(O.kl_divergence(p, q), rel=1e-4)
+
+
+def test_sac_sgd_step_uses_the_entering_training_state():
+    """brax 0.12.1 sac/train.py sgd_step: alpha, critic and actor losses are all evaluated at the training state as it entered
+    the step (alpha before the alpha update, the actor against the critic before the critic update); the target critic then
+    tracks the new critic.  One step against a by-hand replay of that order on clones, and against the sequential order
+    (each loss after the previous update), which must come out different."""
+    import copy
+    from rsr_mjx_amd.learning.sac_train import TwinQ, _mlp, sgd_step
+    torch.manual_seed(3)
+    Do, A, B, tau = 6, 2, 32, 0.05
+    rng = np.random.default_rng(3)
+    f = lambda *s: torch.as_tensor(rng.normal(size=s), dtype=torch.float32)
+    tr = Transition(f(B, Do), torch.tanh(f(B, A)), f(B), torch.ones(B), f(B, Do), {"state_extras": {"truncation": torch.zeros(B)}})
+    noises = (f(B, A), f(B, A), f(B, A))
+
+    def fresh():
+        torch.manual_seed(11)
+        pol = _mlp([Do, 16, 2 * A], None)
+        q, tq = TwinQ(Do, A, (16,), None), TwinQ(Do, A, (16,), None)
+        for a, b in zip(tq.parameters(), q.parameters()):
+            a.data.copy_(b.data)
+        la = torch.full((), 0.3, requires_grad=True)
+        losses = S.make_losses(lambda o: pol(o), lambda o, a: q(o, a), 1.0, 0.95, A)
+        opts = (torch.optim.Adam([la], lr=3e-2), torch.optim.Adam(q.parameters(), lr=3e-2), torch.optim.Adam(pol.parameters(), lr=3e-2))
+        return pol, q, tq, la, losses, opts
+    flat = lambda mod: torch.cat([p.detach().reshape(-1) for p in mod.parameters()])
+
+    pol, q, tq, la, losses, opts = fresh()
+    sgd_step(la, q, tq, pol, lambda o, a: q(o, a), lambda o, a: tq(o, a), losses, opts, tr, noises, tau)
+    got = (la.detach().clone(), flat(q), flat(pol), flat(tq))
+
+    # by hand, brax's order
+    pol, q, tq, la, (alpha_loss, critic_loss, actor_loss), (oa, oq, op) = fresh()
+    tq0 = flat(tq)
+    alpha0 = torch.exp(la).detach()
+    g_a = torch.autograd.grad(alpha_loss(la, tr, noises[0]), la)[0]
+    g_q = torch.autograd.grad(critic_loss(lambda o, a: q(o, a), lambda o, a: tq(o, a), alpha0, tr, noises[1]), list(q.parameters()))
+    g_p = torch.autograd.grad(actor_loss(lambda o, a: q(o, a), alpha0, tr, noises[2]), list(pol.parameters()))
+    la.grad = g_a
+    for p_, g in zip(q.parameters(), g_q): p_.grad = g
+    for p_, g in zip(pol.parameters(), g_p): p_.grad = g
+    oa.step(); oq.step(); op.step()
+    want_tq = (1 - tau) * tq0 + tau * flat(q)
+    for a, b in zip(got, (la.detach(), flat(q), flat(pol), want_tq)):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+
+    # the sequential order (what this module did before) gives another actor and critic
+    pol, q, tq, la, (alpha_loss, critic_loss, actor_loss), (oa, oq, op) = fresh()
+    oa.zero_grad(); alpha_loss(la, tr, noises[0]).backward(); oa.step()
+    alpha1 = torch.exp(la).detach()
+    oq.zero_grad(); critic_loss(lambda o, a: q(o, a), lambda o, a: tq(o, a), alpha1, tr, noises[1]).backward(); oq.step()
+    op.zero_grad(); actor_loss(lambda o, a: q(o, a), alpha1, tr, noises[2]).backward(inputs=list(pol.parameters())); op.step()
+    assert (flat(pol) - got[2]).abs().max() > 1e-5 and (flat(q) - got[1]).abs().max() > 1e-6
+
+
+def test_checkpoint_keeps_the_critics_own_normaliser(tmp_path):
+    """The critic of the Go2 recipe reads `privileged_state` through its own running normaliser (ppo_train: value_obs_key); the
+    reference checkpoints the statistics of every observation key.  Save / load must give the same value function."""
+    from rsr_mjx_amd.learning.checkpoint import load_params, save_params
+    from rsr_mjx_amd.learning.ppo_train import PPONetworks, RunningStatistics, make_mlp
+    torch.manual_seed(1)
+    def build():
+        net = PPONetworks(6, 2)
+        net.value = make_mlp([9, 16, 1], None)
+        net.value_normalizer = RunningStatistics(9)
+        return RunningStatistics(6), net
+    na, a = build()
+    nb, b = build()
+    na.update(torch.randn(40, 6) * 2 + 1)
+    a.value_normalizer.update(torch.randn(70, 9) * 5 - 3)
+    vobs = torch.randn(8, 9) * 5 - 3
+    va = a.value(a.value_normalizer.normalize(vobs))
+    assert not torch.allclose(va, b.value(b.value_normalizer.normalize(vobs)))
+    save_params(str(tmp_path / "c.npz"), (na, a))
+    load_params(str(tmp_path / "c.npz"), (nb, b))
+    assert torch.equal(va, b.value(b.value_normalizer.normalize(vobs))) and b.value_normalizer.count.item() == 70
+    # a checkpoint without those statistics is refused rather than silently restarting the critic's normaliser
+    a.value_normalizer = None
+    save_params(str(tmp_path / "d.npz"), (na, a))
+    with pytest.raises(KeyError):
+        load_params(str(tmp_path / "d.npz"), (nb, b))

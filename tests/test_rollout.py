@@ -177,3 +177,41 @@ def test_pipelined_unroll_on_the_stepper():
     for x, y in ((data.observation, ref.observation), (data.action, ref.action), (data.reward, ref.reward), (data.discount, ref.discount),
                  (data.next_observation, ref.next_observation), (data.extras["state_extras"]["truncation"], ref.extras["state_extras"]["truncation"])):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_unroll_on_the_stepper_matches_an_oracle_stepped_unroll():
+    """f1: `generate_unroll` over the HIP stepper (RSR/train.py:310-330 via brax acting.generate_unroll) against the same unroll
+    stepped by the CPU oracle: same keys, the same deterministic policy evaluated on each side's own observations (closed
+    loop), Episode + AutoReset on both.  Five steps from reset: the trajectories stay within rounding of each other, and the
+    Transition bookkeeping (obs_t, action_t, reward_{t+1}, discount = 1 - done_{t+1}, next obs after auto-reset, truncation)
+    is the oracle's."""
+    import torch
+    from oracle import oracle as O
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.envs.airbot import AirbotPlayBase, wrap
+    from rsr_mjx_amd.rollout import generate_unroll
+    n, T, L = 64, 5, 3                                   # episode_length 3: the unroll crosses a truncation + auto-reset
+    env = wrap(AirbotPlayBase(device="cuda:0"), n, episode_length=L)
+    orc = O.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(77), n)
+    st = orc.new_state(n); orc.reset(st, keys)
+    state = env.reset(keys)
+    W = np.random.default_rng(5).normal(size=(23, 5)).astype(np.float32) * 0.5
+    Wt = torch.as_tensor(W, device="cuda:0")
+    policy = lambda obs, key: (torch.tanh(obs @ Wt), {})
+    state, tr = generate_unroll(env, state, policy, prng.PRNGKey(1), T, extra_fields=("truncation",))
+    torch.cuda.synchronize()
+    err = lambda a, b: np.abs(a - b).reshape(n, -1).max(axis=1) / np.maximum(1.0, np.abs(b).reshape(n, -1).max(axis=1))
+    for t in range(T):
+        obs = st["obs"].copy()
+        act = np.tanh(obs @ W).astype(np.float32)
+        orc.step(st, act)
+        g = lambda x: x[t].cpu().numpy()
+        np.testing.assert_array_equal(g(tr.discount), 1.0 - st["done"])
+        np.testing.assert_array_equal(g(tr.extras["state_extras"]["truncation"]), st["info_truncation"])
+        assert ((t + 1) % L == 0) == bool(st["info_truncation"].all())
+        for name, got, want in (("observation", g(tr.observation), obs), ("action", g(tr.action), act), ("reward", g(tr.reward), st["reward"]),
+                                ("next_observation", g(tr.next_observation), st["obs"])):
+            e = err(got, want)
+            assert np.quantile(e, 0.9) <= 2e-5 and e.max() <= 5e-3, (t, name, float(np.quantile(e, 0.9)), float(e.max()))
