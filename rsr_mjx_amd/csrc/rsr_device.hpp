@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace rsr {
 
@@ -141,6 +142,15 @@ struct Dims {
   // dofs [ISO0, ISO1) never share a constraint row or a kinematic chain with the others (the Airbot target body: it only
   // touches static geoms), so those entries of M, H and their Cholesky factors are structural zeros; checked on the host.
   static constexpr int ISO0 = ISO0_, ISO1 = ISO1_;
+  // Row-blocked factorisation: the Hessian is block diagonal over {dofs outside the isolated range} and {the isolated dofs}; when
+  // both blocks have at most 16 dofs each sits in one 16-lane DPP row (block A in lanes 0.., block B in lanes 16..) and the
+  // factorisation broadcasts within rows (row_newbcast) instead of through v_readlane and SGPRs.  NCH = columns a lane keeps.
+  static constexpr int NISO = ISO1_ - ISO0_;
+  static constexpr int NA = NV_ - NISO;
+  static constexpr bool ROWCHOL = NA <= 16 && NISO <= 16 && NA >= NISO;
+  static constexpr int NCH = ROWCHOL ? NA : NV_;
+  static constexpr int dof_of_col_a(int c) { return c < ISO0_ ? c : c + NISO; }      // block A column -> dof
+  static constexpr int dof_of_col_b(int c) { return ISO0_ + c; }                     // block B column -> dof
   static constexpr bool coupled(int i, int j) { return (i >= ISO0_ && i < ISO1_) == (j >= ISO0_ && j < ISO1_); }
   // with an isolated range the dofs before it, inside it and after it are three separate kinematic trees (checked on the
   // host): the mass matrix alone is block diagonal over them
@@ -771,6 +781,119 @@ __device__ __forceinline__ float chol_solve(const float (&a)[C::NV], const float
 #pragma unroll
   for (int k = C::NV - 1; k >= 0; --k) x -= lt[k] * rdlane(x, k);    // backward, unit upper: lanes >= k hold lt[k] = 0
   return x;
+}
+
+// =====================================================================================
+// Row-blocked L D L^T (Dims::ROWCHOL).  Lane L = (block L >> 4, row L & 15) holds row `L & 15` of its block: a[c] = H[dof(L)][dof of
+// column c of that block].  One factorisation step is: pivot = row_newbcast:k of a[k] (DPP, within each 16-lane row: both blocks
+// at once), reciprocal, and ONE v_fmac_f32_dpp per trailing column (a[j] += row_newbcast:j(u) * -a[k]) -- against v_readlane +
+// s_nop + v_fma (or a packed pair) per column through SGPRs before.  Same operations on the same operands in the same order:
+// the factors are bit-identical to chol_factor's.  Inline asm is opaque to the hazard recogniser, so every DPP read of a
+// register an asm statement (or anything else) may just have written is preceded by its two wait states (s_nop 1).
+// Lanes outside the blocks (and block B's columns past its size) hold zeros throughout.
+// =====================================================================================
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int K> __device__ __forceinline__ float row_bcast(float v) {          // lane K of each 16-lane row, to the whole row
+  float r;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
+template <int K, bool WAIT> __device__ __forceinline__ void fmac_row_bcast(float& acc, float src, float mul) {   // acc += bcast_K(src) * -mul
+  if constexpr (WAIT) asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+  else asm volatile("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fmac_self_bcast(float& x, float mul) {                           // x += bcast_K(x) * -mul
+  asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x) : "v"(mul), "n"(K));
+}
+template <class C> __device__ __forceinline__ int rowchol_dof(int lane) {       // dof of a lane, -1 outside the blocks
+  const int r = lane & 15;
+  if (lane < 16) return r < C::NA ? (r < C::ISO0 ? r : r + C::NISO) : -1;
+  return (lane < 32 && r < C::NISO) ? C::ISO0 + r : -1;
+}
+template <class C> __device__ __forceinline__ int rowchol_lane(int dof) {       // lane of a dof
+  return dof < C::ISO0 ? dof : (dof < C::ISO1 ? 16 + dof - C::ISO0 : dof - C::NISO);
+}
+// Loads this lane's row from a natural-order [NV][LD] matrix in LDS (entries it does not own come from a zero word), adds
+// `diag` to its diagonal, factors.  lt[] = the transposed factor's row, through the LDS scratch `T` (>= NCH * 22 floats).
+template <class C, bool MASS_ONLY, bool HAS_DIAG = false>
+__device__ __forceinline__ float rowchol_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
+  static_assert(C::ROWCHOL, "row-blocked factorisation needs both blocks within 16 lanes");
+  const int r = lane & 15, dofl = rowchol_dof<C>(lane);
+  const bool in_a = lane < 16 && dofl >= 0, in_b = lane >= 16 && dofl >= 0;
+  // One exec region per block with compile-time column offsets (an address select per entry costs a VGPR each and the
+  // kernel has none to spare); entries a lane does not own are zero
+#pragma unroll
+  for (int c = 0; c < C::NCH; ++c) a[c] = 0.0f;
+  if (in_a) {
+    const float* row = src + dofl * C::LD;
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) a[c] = row[C::dof_of_col_a(c)];
+  } else if (in_b) {
+    const float* row = src + dofl * C::LD;
+#pragma unroll
+    for (int c = 0; c < C::NISO; ++c) a[c] = row[C::dof_of_col_b(c)];
+  }
+  if constexpr (HAS_DIAG) {
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) if (c == r) a[c] += diag;           // (diag is zero for lanes outside the blocks)
+  }
+  float dinv = 0.0f;
+  static_for<0, C::NCH>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    float piv = row_bcast<k>(a[k]);
+    piv = piv > 0.0f ? piv : RSR_MINVAL;
+    float rcp = __builtin_amdgcn_rcpf(piv);
+    rcp = rcp + rcp * (1.0f - piv * rcp);
+    if (r == k) dinv = rcp;
+    const float u = a[k];
+    a[k] = (r > k) ? u * rcp : 0.0f;
+    const float lik = a[k];
+    bool first = true;
+    static_for<k + 1, C::NCH>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // structural zeros fold at compile time: block A's columns j, k are dofs; the mass matrix alone is block diagonal over
+      // the kinematic trees inside block A as well (block B is one tree)
+      constexpr bool live = MASS_ONLY ? C::same_tree(C::dof_of_col_a(j), C::dof_of_col_a(k)) : true;
+      if constexpr (live) {
+        if (first) { fmac_row_bcast<j, true>(a[j], u, lik); first = false; }
+        else fmac_row_bcast<j, false>(a[j], u, lik);
+      }
+    });
+  });
+  // transpose through LDS: T[c][L] = a[c] = L[row of L][c]; lt[k] of lane (b, i) = L[k][i] = a[i] of lane (b, k)
+  constexpr int TS = 22;
+  if (lane < TS) {
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) T[c * TS + lane] = a[c];
+  }
+  WSYNC();
+#pragma unroll
+  for (int k = 0; k < C::NCH; ++k) lt[k] = 0.0f;
+  if (in_a) {
+    const float* col = &T[r * TS];
+#pragma unroll
+    for (int k = 0; k < C::NCH; ++k) lt[k] = col[k];
+  } else if (in_b) {
+    const float* col = &T[r * TS + 16];
+#pragma unroll
+    for (int k = 0; k < C::NISO; ++k) lt[k] = col[k];
+  }
+  WSYNC();
+  return dinv;
+}
+// Solves with the row-blocked factor.  b / result: natural order (lane i = dof i); the two permutations are ds_bpermutes.
+template <class C>
+__device__ __forceinline__ float rowchol_solve(const float (&a)[C::NCH], const float (&lt)[C::NCH], float dinv, float b, int lane) {
+  const int dofl = rowchol_dof<C>(lane);
+  float x = __shfl(b, dofl >= 0 ? dofl : 0);
+  x = dofl >= 0 ? x : 0.0f;
+  static_for<0, C::NCH>([&](auto kc) { constexpr int k = decltype(kc)::value; fmac_self_bcast<k>(x, a[k]); });          // forward: lanes <= k hold a[k] = 0
+  x *= dinv;
+  static_for<0, C::NCH>([&](auto kc) { constexpr int k = C::NCH - 1 - decltype(kc)::value; fmac_self_bcast<k>(x, lt[k]); });   // backward
+  return __shfl(x, lane < C::NV ? rowchol_lane<C>(lane) : 0);
 }
 
 // broadcast a per-dof vector (lane i holds v_i) and multiply by a register-resident matrix row

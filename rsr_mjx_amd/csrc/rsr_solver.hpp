@@ -232,7 +232,7 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
 //    all contacts are visited (an all-inactive pyramid has W = 0), which keeps the loop free of index loads.
 template <class C>
 __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
-                                               float (&a)[C::NV], float (&lt)[C::NV] PROF_ARG) {
+                                               float (&a)[C::NCH], float (&lt)[C::NCH] PROF_ARG) {
   constexpr int NBLK = (C::NV + 1) / 2;
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
@@ -300,6 +300,14 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   // Row `lane` of T, unmasked: chol_factor never consumes a[j] of a lane < j before zeroing it, and lanes >= NV (which
   // read row 0) are never read by anyone.  (A select on the loaded value makes the compiler wrap every load in its own
   // exec-mask region with a wait inside: 20 serialised LDS round trips.)
+  if constexpr (C::ROWCHOL) {
+    // the row-blocked factorisation reads its (permuted) rows from T and later writes its transpose to T: one wave, LDS
+    // operations in order, and the rows are in registers (waited for) before the factor loop that precedes the writes
+    PROF(PS_H_XCHG)
+    const float dinv = rowchol_factor<C, false>(s.T, 0.0f, a, lt, s.T, lane);
+    PROF(PS_H_CHOL)
+    return dinv;
+  } else {
   const float* Trow = &s.T[(lane < C::NV ? lane : 0) * C::LD];
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) a[j] = Trow[j];
@@ -308,6 +316,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   const float dinv = chol_factor<C>(a, lt, s.T, lane);
   PROF(PS_H_CHOL)
   return dinv;
+  }
 }
 
 struct SolveStats { int niter, ls_total; };
@@ -332,7 +341,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
                       SolveStats& st, float* dbg PROF_ARG) {
   const bool dofl = lane < C::NV;
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
-  float a[C::NV], lt[C::NV];
+  float a[C::NCH], lt[C::NCH];
   // --- warm start: the cheaper of qacc_warmstart and qacc_smooth (cost only) ---
   // qacc_smooth is costed first so that the force / weight registers hold the warm-start point afterwards: the warm start
   // wins almost always, and its context (row cost, Gauss term, force, hw) is then already there instead of being
@@ -401,7 +410,10 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
       for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = hw[ch];
       have_factor = true;
     }
-    const float search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
+    float search;
+    if constexpr (C::ROWCHOL) search = -rowchol_solve<C>(a, lt, dinv, grad, lane);
+    else search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
+    search = dofl ? search : 0.0f;
     PROF(PS_HESS)
     // ---------------- line search ----------------
     float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
@@ -538,11 +550,18 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   float fs = smooth_forces<C>(m, h, s, lane, qvel_i, 0.0f);
   PROF(PS_SMOOTH)
   // qacc_smooth = M^-1 qfrc_smooth
-  float a[C::NV], lt[C::NV];
+  float a[C::NCH], lt[C::NCH];
+  float a0;
+  if constexpr (C::ROWCHOL) {
+    const float dinv_m = rowchol_factor<C, true>(s.M, 0.0f, a, lt, s.T, lane);
+    a0 = rowchol_solve<C>(a, lt, dinv_m, fs, lane);
+    a0 = lane < C::NV ? a0 : 0.0f;
+  } else {
 #pragma unroll
-  for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j];        // entries j > lane are never consumed by chol_factor
-  const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
-  float a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
+    for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j];        // entries j > lane are never consumed by chol_factor
+    const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
+    a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
+  }
   PROF(PS_CHOLM)
   collision<C>(m, h, s, lane PROF_PASS);
   PROF(PS_COLL)
@@ -605,12 +624,20 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
   float qacc = f.qacc;
   const bool implicit = implicit_integration<C>(m, s, lane);
   if (implicit) {
-    float a[C::NV], lt[C::NV];
+    float a[C::NCH], lt[C::NCH];
+    if constexpr (C::ROWCHOL) {
+      const int dl = rowchol_dof<C>(lane);
+      const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
+      const float dinv_i = rowchol_factor<C, true, true>(s.M, dd, a, lt, s.T, lane);
+      qacc = rowchol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane);
+      qacc = lane < C::NV ? qacc : 0.0f;
+    } else {
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j] + (j == lane ? dd : 0.0f);
     const float dinv_i = chol_factor<C, true>(a, lt, s.T, lane);
     qacc = lane < C::NV ? chol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane) : 0.0f;
+    }
   }
   WSYNC();
   if (lane < C::NV) s.qvel[lane] += qacc * m.timestep;
