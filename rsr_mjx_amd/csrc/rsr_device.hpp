@@ -999,12 +999,10 @@ __device__ __forceinline__ void plane_box_sat(V3 pp, const float* pm, V3 bp, con
   job.kind = 1; job.o = pp; job.nref = n; job.axu = col(pm, 0); job.axv = col(pm, 1);
   job.bp = bp; job.size = size; job.bm = bm_lds; job.hu = smax;
 }
-__device__ void plane_box_clip(const ClipJob& job, float* scr, CPts& out) {
-  float* sup = scr; float* vx = scr + 8; float* vy = scr + 16;
-  for (int v = 0; v < 8; ++v) {
-    V3 w = box_vertex(job.bm, job.bp, job.size, v);
-    sup[v] = dot(job.o - w, job.nref); vx[v] = dot(w, job.axu); vy[v] = dot(w, job.axv);
-  }
+// The owner lane's part of a plane-box manifold: supports and in-plane coordinates of the eight vertices are in scr (written
+// one vertex per lane by collision()); vertices within 1 mm of the deepest, <= 4 of them by manifold_points.
+__device__ void plane_box_finish(const ClipJob& job, const float* scr, CPts& out) {
+  const float* sup = scr; const float* vx = scr + 8; const float* vy = scr + 16;
   float thr = fmaxf(job.hu - 1e-3f, 0.0f);
   unsigned mask = 0;
   for (int v = 0; v < 8; ++v) if (sup[v] > thr) mask |= 1u << v;
@@ -1127,38 +1125,10 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
   job.kind = 2; job.o = o; job.nref = nref; job.axu = axu; job.axv = axv; job.hu = hu; job.hv = hv; job.flip = !ref_is_a;
 }
 
-// Sutherland-Hodgman of the incident face against the reference rectangle, then <=4 manifold points.
-// scr: 48 floats (two ping-pong polygons of <=8 (x, y, depth) points).
-__device__ void box_box_clip(const ClipJob& job, float* scr, CPts& out) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { scr[i] = job.px[i]; scr[8 + i] = job.py[i]; scr[16 + i] = job.pd[i]; }
-  int np = 4, cur = 0;
-  for (int side = 0; side < 4; ++side) {
-    float h = (side < 2) ? job.hu : job.hv;
-    float sg = (side & 1) ? -1.0f : 1.0f;
-    float* P = scr + cur * 24; float* Qn = scr + (1 - cur) * 24;
-    // the current vertex is carried in registers and the next one is loaded before anything is stored: stores to the
-    // other polygon may alias as far as the compiler knows, and a load issued after them waits for its own round trip
-    float x1 = P[0], y1 = P[8], z1 = P[16];
-    int nn = 0;
-    for (int i = 0; i < np; ++i) {
-      const int i2 = (i + 1 == np) ? 0 : i + 1;
-      const float x2 = P[i2], y2 = P[8 + i2], z2 = P[16 + i2];
-      float d1 = h - sg * (side < 2 ? x1 : y1), d2 = h - sg * (side < 2 ? x2 : y2);
-      if (d1 >= 0.0f) { Qn[nn] = x1; Qn[8 + nn] = y1; Qn[16 + nn] = z1; nn++; }
-      if ((d1 >= 0.0f) != (d2 >= 0.0f)) {
-        float tt = d1 / (d1 - d2);
-        Qn[nn] = x1 + tt * (x2 - x1);
-        Qn[8 + nn] = y1 + tt * (y2 - y1);
-        Qn[16 + nn] = z1 + tt * (z2 - z1);
-        nn++;
-      }
-      x1 = x2; y1 = y2; z1 = z2;
-    }
-    np = nn; cur = 1 - cur;
-    if (np == 0) return;
-  }
-  float* P = scr + cur * 24;
+// The owner lane's part of a box-box face manifold: P = the incident face clipped against the reference rectangle (np points:
+// x[8], y[8], depth[8], written by collision()'s four lane-per-vertex passes); <= 4 penetrating points by manifold_points.
+__device__ void box_box_finish(const ClipJob& job, const float* P, int np, CPts& out) {
+  if (np == 0) return;
   unsigned mask = 0;
   for (int i = 0; i < np; ++i) if (P[16 + i] > 0.0f) mask |= 1u << i;
   if (!mask) return;
@@ -1284,16 +1254,87 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
     }
   }
   PROF(PS_X0)
-  // manifolds of the touching pairs, NSLOT at a time (usually one round: few pairs touch)
-  unsigned long long pend = __ballot(job.kind != 0);
-  while (pend) {
-    int rank = __popcll(pend & ((1ull << lane) - 1ull));
-    if (job.kind != 0 && rank < NSLOT) {
-      float* scr = &s.x.a.clip[rank * 48];
-      if (job.kind == 1) plane_box_clip(job, scr, pts); else box_box_clip(job, scr, pts);
-      job.kind = 0;
+  // Manifolds of the touching pairs, eight at a time, EIGHT LANES PER PAIR (lane = 8 * slot + vertex).  The owner lane of a
+  // pending pair publishes its job in LDS; the plane-box supports / the Sutherland-Hodgman passes then run with one lane per
+  // polygon vertex -- a pass is one batch of loads, a few compares, two ballots for the output positions and one batch of
+  // stores, instead of a serial walk over the vertices with a dependent LDS round trip each (that walk was 7 % of the
+  // kernel's cycles); the owner lane finishes with the <= 4-point manifold selection.  Same arithmetic per vertex and the
+  // same output order (kept vertex, then the edge's intersection), so the contacts are bit-identical.
+  if constexpr (C::CONDIM != 3) {
+    constexpr int GS = 8;                                    // pairs per round
+    float* const poly = s.x.a.clip;                          // [GS][2][24]: ping-pong polygons (x[8], y[8], depth[8])
+    float* const par = s.x.a.clip + GS * 48;                 // [GS][32]: job parameters, [30] = final vertex count, [31] = kind
+    unsigned long long pend = __ballot(job.kind != 0);
+    while (pend) {
+      const int rank = __popcll(pend & ((1ull << lane) - 1ull));
+      const bool mine = job.kind != 0 && rank < GS;
+      if (mine) {
+        float* q = par + rank * 32;
+        q[31] = (float)job.kind;
+        if (job.kind == 1) {
+          st3(q, job.bp); st3(q + 3, job.size);
+#pragma unroll
+          for (int c = 0; c < 9; ++c) q[6 + c] = job.bm[c];
+          st3(q + 15, job.o); st3(q + 18, job.nref); st3(q + 21, job.axu); st3(q + 24, job.axv);
+        } else {
+          q[0] = job.hu; q[1] = job.hv;
+          float* P0 = poly + rank * 48;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { P0[i] = job.px[i]; P0[8 + i] = job.py[i]; P0[16 + i] = job.pd[i]; }
+        }
+      }
+      const int nslots = __popcll(pend) < GS ? __popcll(pend) : GS;
+      WSYNC();
+      {
+        const int slot = lane >> 3, v = lane & 7;
+        const float* q = par + slot * 32;
+        const int kind = slot < nslots ? (int)q[31] : 0;
+        float* P = poly + slot * 48;
+        if (kind == 1) {                                     // plane-box: vertex v's support and in-plane coordinates
+          V3 bp = ld3(q), size = ld3(q + 3), o = ld3(q + 15), nref = ld3(q + 18), axu = ld3(q + 21), axv = ld3(q + 24);
+          V3 w = box_vertex(q + 6, bp, size, v);
+          P[v] = dot(o - w, nref); P[8 + v] = dot(w, axu); P[16 + v] = dot(w, axv);
+        }
+        // box-box: four clipping passes against the reference rectangle
+        const bool bb = kind == 2;
+        const float hu = bb ? q[0] : 0.0f, hv = bb ? q[1] : 0.0f;
+        int np = bb ? 4 : 0, cur = 0;
+        const unsigned long long slotbits = 0xFFull << (8 * slot), below = slotbits & ((1ull << lane) - 1ull);
+        const bool any_bb = __ballot(bb) != 0ull;
+        if (any_bb) {
+          for (int side = 0; side < 4; ++side) {
+            const float h = (side < 2) ? hu : hv, sg = (side & 1) ? -1.0f : 1.0f;
+            const float* Pc = P + cur * 24; float* Qn = P + (1 - cur) * 24;
+            const bool act = bb && v < np;
+            const int v1 = act ? v : 0, v2 = act ? ((v + 1 == np) ? 0 : v + 1) : 0;
+            const float x1 = Pc[v1], y1 = Pc[8 + v1], z1 = Pc[16 + v1], x2 = Pc[v2], y2 = Pc[8 + v2], z2 = Pc[16 + v2];
+            const float d1 = h - sg * (side < 2 ? x1 : y1), d2 = h - sg * (side < 2 ? x2 : y2);
+            const bool e1 = act && d1 >= 0.0f, e2 = act && ((d1 >= 0.0f) != (d2 >= 0.0f));
+            const unsigned long long b1 = __ballot(e1), b2 = __ballot(e2);
+            const int pos = __popcll(b1 & below) + __popcll(b2 & below);
+            if (e1) { Qn[pos] = x1; Qn[8 + pos] = y1; Qn[16 + pos] = z1; }      // (the reads were from the other buffer)
+            if (e2) {
+              const float tt = d1 / (d1 - d2);
+              const int pi = pos + (e1 ? 1 : 0);
+              Qn[pi] = x1 + tt * (x2 - x1); Qn[8 + pi] = y1 + tt * (y2 - y1); Qn[16 + pi] = z1 + tt * (z2 - z1);
+            }
+            np = bb ? __popcll(b1 & slotbits) + __popcll(b2 & slotbits) : 0;
+            cur = 1 - cur;
+            WSYNC();
+          }
+          if (bb && v == 0) par[slot * 32 + 30] = (float)np;
+        }
+      }
+      WSYNC();
+      if (mine) {
+        float* scr = poly + rank * 48;
+        if (job.kind == 1) plane_box_finish(job, scr, pts);
+        else box_box_finish(job, scr, (int)par[rank * 32 + 30], pts);      // four passes: the result is back in the first buffer
+        job.kind = 0;
+      }
+      WSYNC();
+      pend = __ballot(job.kind != 0);
     }
-    pend = __ballot(job.kind != 0);
   }
   PROF(PS_X1)
   // keep penetrating contacts only (result-neutral culling), compact in pair order
