@@ -38,6 +38,7 @@ struct DModel {
   const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
   const int *geom_bodyid, *geom_priority;
   const float *geom_size, *geom_pos, *geom_quat, *geom_friction;
+  const int* geom_slot_ids;      // geom id of every geom slot (the geoms that appear in a contact pair, in geom order)
   const int *site_bodyid;
   const float *site_pos, *site_quat;
   const int *eq_obj1id, *eq_obj2id, *eq_active0;
@@ -132,8 +133,16 @@ struct StepArgs {
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
-          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false>
+          int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false,
+          bool TALIAS_ = false, int NGA_ = NG_>
 struct Dims {
+  // LDS diet of the single-iteration models (Go2: one Hessian per substep, explicit Euler): the transpose / exchange scratch T
+  // has no storage of its own -- before the solve it is the dead part of phase A (cinert .. cfrcsum), from the Hessian on it
+  // is the mass matrix's storage (M is read for the last time when the Hessian blocks are formed) -- and geom frames /
+  // friction are kept for the NGA geoms that appear in a contact pair only (slots; Go2: floor or height field + four feet of
+  // 39 geoms).  Together 13.4 KB -> under 10 KB per env: a fourth wave per SIMD.
+  static constexpr bool TALIAS = TALIAS_;
+  static constexpr int NGA = NGA_;
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
   static constexpr bool XFRC = NINFO_ > 0;           // xfrc_applied on one body and the accelerometer bias are compiled in (Go2)
@@ -352,7 +361,7 @@ template <class C>
 struct PhaseA {
   float xmat[C::NB * 9], xipos[C::NB * 3], ximat[C::NB * 9];
   float xanchor[C::NJ * 3], xaxis[C::NJ * 3];
-  float gpos[C::NG * 3], gmat[C::NG * 9];
+  float gpos[C::NGA * 3], gmat[C::NGA * 9];
   float cinert[C::NB * 10], crb[C::NB * 10];
   float cvel[C::NB * 6], cdofdot[C::NV * 6], cfrc[C::NB * 6], cfrcsum[C::NB * 6];
   float clip[(C::CONDIM == 3 ? 1 : NSLOT) * 48];     // condim-3 models here are sphere-only (Go2): no clipping, one dummy slot
@@ -363,9 +372,10 @@ struct PhaseB {
 };
 template <class C>
 struct Smem {
+  static_assert(!C::TALIAS || (C::NB * 10 * 2 + C::NB * 6 >= C::NV * (C::NV + 1)), "phase A's dead arrays must hold the transpose scratch");
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
-  float fric[C::NG * 3], mass[C::NB], damp[C::NV], floss[C::NV];
+  float fric[C::NGA * 3], mass[C::NB], damp[C::NV], floss[C::NV];
   // extended per-env overrides (Dims::DREX; one-element placeholders otherwise)
   float dx_ipos[C::DREX ? C::NB * 3 : 1], dx_qpos0[C::DREX ? C::NQ : 1], dx_arma[C::DREX ? C::NV : 1];
   float dx_gain[C::DREX ? C::NU * 3 : 1], dx_bias[C::DREX ? C::NU * 3 : 1];
@@ -379,7 +389,9 @@ struct Smem {
   int xfrc_body, acc_body;
   float ginfo[C::NINFO > 0 ? C::NINFO : 1];            // env info block staged in LDS for the whole step (Go2)
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
-  float M[C::NV * C::LD], T[C::NV * C::LD];
+  float M[C::NV * C::LD], T_store[C::TALIAS ? 1 : C::NV * C::LD];
+  __device__ __forceinline__ float* scratch_a() { if constexpr (C::TALIAS) return x.a.cinert; else return T_store; }   // phase A: mass-matrix factor transposes
+  __device__ __forceinline__ float* scratch_b() { if constexpr (C::TALIAS) return M; else return T_store; }            // Hessian exchange / transposes; env scratch
   // contacts (active only)
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
   int cpair[C::NCON];
@@ -416,7 +428,7 @@ enum LaneQuad { LQ_B_IDS = 0, LQ_B_POS, LQ_B_QUAT, LQ_B_JPOS, LQ_B_JAX, LQ_B_IQU
 // number of lanes that hold data in a quad's row (its role's count); the lanes past it hold zeros
 template <class C>
 __device__ __forceinline__ constexpr int lq_count(int quad) {
-  return quad < LQ_J_IDS ? C::NB : quad < LQ_G_POS ? C::NJ : quad < LQ_S_POS ? C::NG : quad < LQ_D_IDS ? C::NS : quad < LQ_F_0 ? C::NV
+  return quad < LQ_J_IDS ? C::NB : quad < LQ_G_POS ? C::NJ : quad < LQ_S_POS ? C::NGA : quad < LQ_D_IDS ? C::NS : quad < LQ_F_0 ? C::NV
        : quad < LQ_L_0 ? C::NF : quad < LQ_P_0 ? C::NL : quad < LQ_E_0 ? C::NP : C::NEQ;
 }
 // Lanes past the role's count all read the first zero entry of the row instead of their own: a row then occupies
@@ -522,7 +534,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
       st3(&s.x.a.xaxis[3 * j], qrot(qpre, V3{asf(rj_posax.z), asf(rj_posax.w), asf(rj_ax.x)}));
     }
   }
-  if (lane < C::NG) {
+  if (lane < C::NGA) {          // geom slots: the geoms that appear in a contact pair (all of them unless Dims::NGA says otherwise)
     const int g = lane, gb = rg_pos.x;
     Q4 gq = ld4(&s.xquat[4 * gb]);
     st3(&s.x.a.gpos[3 * g], ld3(&s.xpos[3 * gb]) + mulv(&s.x.a.xmat[9 * gb], v3_yzw(rg_pos)));

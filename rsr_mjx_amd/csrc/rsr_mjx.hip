@@ -23,7 +23,7 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_N
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
-                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true>;
+                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ true, /*NGA: floor or height field + four feet*/ 5>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
@@ -67,7 +67,10 @@ __device__ __forceinline__ float uniform_from_bits(uint32_t b, float lo, float h
 template <class C>
 __device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, int e, int lane) {
   if (lane < 4) s.rw[C::NEFC + lane] = 0.0f;                 // zero weight of the null row
-  for (int t = lane; t < C::NG * 3; t += 64) s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + t] : m.geom_friction[t];
+  for (int t = lane; t < C::NGA * 3; t += 64) {               // friction of the geom slots (geoms of the contact pairs)
+    const int src = C::NGA == C::NG ? t : 3 * m.geom_slot_ids[t / 3] + t % 3;
+    s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + src] : m.geom_friction[src];
+  }
   if (lane < C::NB) s.mass[lane] = a.dr_body_mass ? a.dr_body_mass[(size_t)e * C::NB + lane] : m.body_mass[lane];
   if (lane < C::NV) {
     s.damp[lane] = a.dr_dof_damping ? a.dr_dof_damping[(size_t)e * C::NV + lane] : m.dof_damping[lane];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
   const float* R = m.env_reset;
   constexpr int JQ = ENV == ENV_TSHAPE ? (int)TID_JOINTQ : (int)ID_JOINTQ;     // arm joint qpos addresses in env_ids
   constexpr int RCTRL = ENV == ENV_TSHAPE ? 7 : 8;                            // ctrl init in env_reset
-  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);         // PRNG scratch
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.scratch_b());         // PRNG scratch
   load_overrides<C>(m, s, a, e, lane);
   const uint32_t k0 = a.keys[2 * e], k1 = a.keys[2 * e + 1];
   random_bits(k0, k1, 10, bits, lane);                        // rng, rng1..rng4 = split(rng, 5)
@@ -471,7 +474,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   }
   // ---- epilogue: reward, done, obs, info; derived data are from the last forward pass ----
   float done = 0.0f;
-  float* obs_lds = s.T;                                     // staged so that auto-reset can override it
+  float* obs_lds = s.scratch_b();                                     // staged so that auto-reset can override it
   if (lane == 0) {
 #pragma clang fp contract(off)
     const float* W = m.env_reward;
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
   if (e >= a.n) return;
   float* rec = a.state + (size_t)e * L.rec;
   const float* F = m.env_go2f;
-  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);
-  float* obs_lds = s.T + 64;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.scratch_b());
+  float* obs_lds = s.scratch_b() + 64;
   load_overrides<C>(m, s, a, e, lane);
   for (int t = lane; t < C::NINFO; t += 64) s.ginfo[t] = 0.0f;
   uint32_t rng0 = a.keys[2 * e], rng1 = a.keys[2 * e + 1], ks[4][2];
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
 // ---------------------------------------------------------------- Go2 step kernel (joystick.py:204-280 + wrappers)
 template <class C>
 #ifndef RSR_GO2_WAVES_PER_EU
-#define RSR_GO2_WAVES_PER_EU 3
+#define RSR_GO2_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_GO2_WAVES_PER_EU, RSR_GO2_WAVES_PER_EU)))
 void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
@@ -711,9 +714,9 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
   const float* F = m.env_go2f;
   const float dt = F[0];
-  uint32_t* bits = reinterpret_cast<uint32_t*>(s.T);
-  float* obs_lds = s.T + 64;
-  float* rwl = s.T + 128;                                   // scaled reward terms staged for the metrics write
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.scratch_b());
+  float* obs_lds = s.scratch_b() + 64;
+  float* rwl = s.scratch_b() + 128;                                   // scaled reward terms staged for the metrics write
   PROF_DECL
   for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
   float warm = 0.0f;
@@ -1111,7 +1114,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   {  // fields read below or by fill_dmodel without a further check
     static const char* const need[] = {"counts2", "opt_integrator", "opt_timestep", "opt_gravity", "opt_tolerance", "opt_ls_tolerance", "opt_impratio",
                                        "stat_meaninertia", "opt_iterations", "opt_ls_iterations", "opt_disable_eulerdamp", "opt_disable_refsafe",
-                                       "pair_condim", "pair_kind", "pair_geom1", "pair_geom2", "geom_size", "eq_active0", "lane_rec"};
+                                       "pair_condim", "pair_kind", "pair_geom1", "pair_geom2", "geom_size", "eq_active0", "lane_rec", "geom_slot_ids"};
     for (const char* f : need) {
       int cnt = 0;
       if (!m->find(f, &cnt) || (cnt < 1 && std::strcmp(f, "pair_condim") && std::strcmp(f, "pair_kind") && std::strcmp(f, "pair_geom1") && std::strcmp(f, "pair_geom2") && std::strcmp(f, "eq_active0"))) {
@@ -1137,6 +1140,24 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
   const int want_condim = d.env_kind == rsr::ENV_GO2 ? 3 : 4;
   if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape, Go2 joystick flat)"); }
   if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
+  {  // geom slots: as many as the kernel's LDS image keeps, each a geom id, every pair geom among them (model.py: geom_slots)
+    int ns = 0, np1 = 0; const int* gs = static_cast<const int*>(m->find("geom_slot_ids", &ns));
+    const int want = d.env_kind == rsr::ENV_GO2 ? rsr::Go2Dims::NGA : (d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::NGA : rsr::CubeDims::NGA);
+    bool okg = gs && ns == want;
+    for (int i = 0; okg && i < ns; ++i) okg = gs[i] >= 0 && gs[i] < d.ngeom && (want != d.ngeom || gs[i] == i);
+    const int* pg1 = static_cast<const int*>(m->find("pair_geom1", &np1)); const int* pg2 = static_cast<const int*>(m->find("pair_geom2"));
+    for (int q = 0; okg && q < np1; ++q) {
+      bool f1 = false, f2 = false;
+      for (int i = 0; i < ns; ++i) { f1 |= gs[i] == pg1[q]; f2 |= gs[i] == pg2[q]; }
+      okg = f1 && f2;
+    }
+    if (!okg) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: geom_slot_ids do not match the kernel's geom slots (Dims::NGA) or miss a pair geom"); }
+  }
+  if (d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::TALIAS) {   // the Go2 kernels reuse the mass matrix's storage after the one Hessian of a substep
+    const int* it = static_cast<const int*>(m->find("opt_iterations"));
+    const int* ig = static_cast<const int*>(m->find("opt_integrator"));
+    if (it[0] != 1 || ig[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the Go2 kernels are built for opt.iterations = 1 and the Euler integrator"); }
+  }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
   for (int i = 0; i < npc; ++i) if (pc[i] != want_condim) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: contact pairs must all have the condim the kernel is built for (Airbot 4, Go2 3)"); }
   int nea = 0; const int* ea = static_cast<const int*>(m->find("eq_active0", &nea));
@@ -1213,7 +1234,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   P(int, dof_bodyid) P(int, dof_jntid)
   P(unsigned, dof_ancmask) P(unsigned, dof_velmask) P(unsigned, body_dofmask) P(unsigned, body_submask)
   P(float, dof_armature) P(float, dof_damping) P(float, dof_frictionloss) P(float, dof_invweight0) P(float, dof_solref) P(float, dof_solimp)
-  P(int, geom_bodyid) P(int, geom_priority) P(float, geom_size) P(float, geom_pos) P(float, geom_quat) P(float, geom_friction)
+  P(int, geom_bodyid) P(int, geom_priority) P(float, geom_size) P(float, geom_pos) P(float, geom_quat) P(float, geom_friction) P(int, geom_slot_ids)
   P(int, site_bodyid) P(float, site_pos) P(float, site_quat)
   P(int, eq_obj1id) P(int, eq_obj2id) P(int, eq_active0) P(float, eq_data) P(float, eq_solref) P(float, eq_solimp)
   P(int, actuator_trnid) P(int, actuator_ctrllimited) P(int, actuator_forcelimited)

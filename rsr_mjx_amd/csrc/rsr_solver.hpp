@@ -293,8 +293,9 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   }
   PROF(PS_H_CONTACT)
   if (blk) {
-    s.T[i0 * C::LD + j0] = h00; s.T[(i0 + 1) * C::LD + j0] = h10; s.T[(i0 + 1) * C::LD + j0 + 1] = h11;
-    if (bi != bj) s.T[i0 * C::LD + j0 + 1] = h01;     // diagonal blocks: (i0, i0+1) is upper, never read
+    float* const Tb = s.scratch_b();
+    Tb[i0 * C::LD + j0] = h00; Tb[(i0 + 1) * C::LD + j0] = h10; Tb[(i0 + 1) * C::LD + j0 + 1] = h11;
+    if (bi != bj) Tb[i0 * C::LD + j0 + 1] = h01;     // diagonal blocks: (i0, i0+1) is upper, never read
   }
   WSYNC();
   // Row `lane` of T, unmasked: chol_factor never consumes a[j] of a lane < j before zeroing it, and lanes >= NV (which
@@ -304,16 +305,16 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     // the row-blocked factorisation reads its (permuted) rows from T and later writes its transpose to T: one wave, LDS
     // operations in order, and the rows are in registers (waited for) before the factor loop that precedes the writes
     PROF(PS_H_XCHG)
-    const float dinv = rowchol_factor<C, false>(s.T, 0.0f, a, lt, s.T, lane);
+    const float dinv = rowchol_factor<C, false>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
     PROF(PS_H_CHOL)
     return dinv;
   } else {
-  const float* Trow = &s.T[(lane < C::NV ? lane : 0) * C::LD];
+  const float* Trow = &s.scratch_b()[(lane < C::NV ? lane : 0) * C::LD];
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) a[j] = Trow[j];
   WSYNC();
   PROF(PS_H_XCHG)
-  const float dinv = chol_factor<C>(a, lt, s.T, lane);
+  const float dinv = chol_factor<C>(a, lt, s.scratch_b(), lane);
   PROF(PS_H_CHOL)
   return dinv;
   }
@@ -553,13 +554,13 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   float a[C::NCH], lt[C::NCH];
   float a0;
   if constexpr (C::ROWCHOL) {
-    const float dinv_m = rowchol_factor<C, true>(s.M, 0.0f, a, lt, s.T, lane);
+    const float dinv_m = rowchol_factor<C, true>(s.M, 0.0f, a, lt, s.scratch_a(), lane);
     a0 = rowchol_solve<C>(a, lt, dinv_m, fs, lane);
     a0 = lane < C::NV ? a0 : 0.0f;
   } else {
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j];        // entries j > lane are never consumed by chol_factor
-    const float dinv_m = chol_factor<C, true>(a, lt, s.T, lane);
+    const float dinv_m = chol_factor<C, true>(a, lt, s.scratch_a(), lane);
     a0 = lane < C::NV ? chol_solve<C>(a, lt, dinv_m, fs, lane) : 0.0f;
   }
   PROF(PS_CHOLM)
@@ -583,7 +584,14 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
       dbg[4] = (float)out.st.niter; dbg[5] = (float)out.st.ls_total; dbg[6] = (float)s.nlim_act; dbg[7] = (float)s.ncon_drop;
     }
     for (int t = lane; t < C::NB * 3; t += 64) dbg[16 + t] = s.xpos[t];
-    for (int t = lane; t < C::NV * C::NV; t += 64) dbg[128 + t] = s.M[(t / C::NV) * C::LD + (t % C::NV)];
+    if constexpr (C::TALIAS) {        // (the mass matrix's LDS storage has been reused since the Hessian: dump the register copy)
+      if (lane < C::NV) {
+#pragma unroll
+        for (int j = 0; j < C::NV; ++j) dbg[128 + lane * C::NV + j] = Mrow[j];
+      }
+    } else {
+      for (int t = lane; t < C::NV * C::NV; t += 64) dbg[128 + t] = s.M[(t / C::NV) * C::LD + (t % C::NV)];
+    }
     if (lane < C::NV) {
       dbg[736 + lane] = fs; dbg[768 + lane] = a0; dbg[800 + lane] = out.qacc; dbg[832 + lane] = out.qfc;
     }
@@ -628,14 +636,14 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
     if constexpr (C::ROWCHOL) {
       const int dl = rowchol_dof<C>(lane);
       const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
-      const float dinv_i = rowchol_factor<C, true, true>(s.M, dd, a, lt, s.T, lane);
+      const float dinv_i = rowchol_factor<C, true, true>(s.M, dd, a, lt, s.scratch_a(), lane);
       qacc = rowchol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane);
       qacc = lane < C::NV ? qacc : 0.0f;
     } else {
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j] + (j == lane ? dd : 0.0f);
-    const float dinv_i = chol_factor<C, true>(a, lt, s.T, lane);
+    const float dinv_i = chol_factor<C, true>(a, lt, s.scratch_a(), lane);
     qacc = lane < C::NV ? chol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane) : 0.0f;
     }
   }

@@ -81,8 +81,21 @@ def model_fields(m: CompiledModel) -> Dict[str, np.ndarray]:
                           int(m.arrays["eq_obj1id"].shape[0]), m.npair], dtype=np.int32)
     topo = topology_tables(m)
     f.update(topo)
-    f["lane_rec"] = lane_records(m, topo)
+    f["geom_slot_ids"] = geom_slots(m)
+    f["lane_rec"] = lane_records(m, topo, f["geom_slot_ids"])
     return f
+
+
+def geom_slots(m: CompiledModel) -> np.ndarray:
+    """Geom ids the kernel keeps world frames and friction for, one per "geom slot".  Every geom, in order -- unless fewer than
+    half of the geoms appear in a contact pair (Go2 feet-only: floor or height field + four feet of 39 geoms), in which case
+    only those, in geom order: the per-env LDS image then holds 5 frames instead of 39.  The kernel's Dims::NGA must match
+    (checked at rsr_model_create)."""
+    A = m.arrays
+    used = sorted(set(int(g) for g in A["pair_geom1"]) | set(int(g) for g in A["pair_geom2"]))
+    if 2 * len(used) < m.ngeom:
+        return np.asarray(used, dtype=np.int32)
+    return np.arange(m.ngeom, dtype=np.int32)
 
 
 def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np.ndarray]:
@@ -135,7 +148,7 @@ def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np
 LANE_QUADS = 41
 
 
-def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
+def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=None) -> np.ndarray:
     """Per-lane constant records for the tree stages of the kernel: int32 [LANE_QUADS][64][4] (floats stored by bit pattern).
 
     In the kernel lane l plays body l, joint l, geom l, site l and dof l.  Fetching that lane's model constants from
@@ -147,14 +160,14 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
              4 (jaxis yz, ipos xy)  5 iquat  6 (ipos z, i rootid, i submask, i dofmask)  7 (inertia xyz, 0)
       joint: 8 (i bodyid, i parent of that body, i type, 0)  9 body_quat[bodyid]  10 (body_pos[bodyid] xyz, jnt_pos x)
              11 (jnt_pos yz, jnt_axis xy)  12 (jnt_axis z, 0, 0, 0)
-      geom : 13 (i bodyid, pos xyz)  14 quat            site : 15 (i bodyid, pos xyz)  16 quat
+      geom : 13 (i bodyid, pos xyz)  14 quat  (indexed by geom SLOT, see geom_slots)      site : 15 (i bodyid, pos xyz)  16 quat
       dof  : 17 (i jntid, i bodyid, i jtype, i k)  18 (i rootid, i ancmask, i velmask, armature)
              19 (i actuator or -1, gear, i qposadr of the joint, i ctrllimited)  20 (ctrl lo, ctrl hi, gainprm0, biasprm0)
              21 (biasprm1, biasprm2, i forcelimited, force lo)  22 (force hi, i actfrclimited, actfrc lo, actfrc hi)
     and, indexed by the constraint-side roles (friction row l, limit slot l, geom pair l, equality l):
       fric : 23 (i dof, invweight0, solref 0 1)  24 (solimp 0..3)  25 (solimp 4, 0, 0, 0)
       limit: 26 (i qposadr, i dofadr, range lo hi)  27 (margin, invweight0, solref 0 1)  28 (solimp 0..3)  29 (solimp 4, i joint, 0, 0)
-      pair : 30 (i geom1, i geom2, i kind, margin - gap)  31 (size[geom1] xyz, tw)  32 (size[geom2] xyz, i friction rule: 0 max,
+      pair : 30 (i slot of geom1, i slot of geom2, i kind, margin - gap)  31 (size[geom1] xyz, tw)  32 (size[geom2] xyz, i friction rule: 0 max,
              1 geom1's, 2 geom2's)  33 (i mask1, i mask2, i root1, i root2)  34 (solref 0 1, solimp 0 1)  35 (solimp 2 3 4, 0)
       eq   : 36 (i active, i qposadr1, i dofadr1, invweight0 sum)  37 (i has obj2, i qposadr2, i dofadr2, 0)  38 (data 0..3)
              39 (data 4, solref 0 1, solimp 0)  40 (solimp 1..4)
@@ -185,10 +198,12 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
         fv[11, j] = [A["jnt_pos"][j][1], A["jnt_pos"][j][2], A["jnt_axis"][j][0], A["jnt_axis"][j][1]]
         fv[12, j, 0] = A["jnt_axis"][j][2]
         rec[12, j, 1:3] = [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
-    for g in range(m.ngeom):
-        rec[13, g, 0] = A["geom_bodyid"][g]
-        fv[13, g, 1:] = A["geom_pos"][g]
-        fv[14, g] = A["geom_quat"][g]
+    slots = np.arange(m.ngeom) if geom_slot_ids is None else np.asarray(geom_slot_ids)
+    slot_of = {int(g): k for k, g in enumerate(slots)}             # geom rows and the pair rows' geom references go by slot
+    for k, g in enumerate(slots):
+        rec[13, k, 0] = A["geom_bodyid"][g]
+        fv[13, k, 1:] = A["geom_pos"][g]
+        fv[14, k] = A["geom_quat"][g]
     for k in range(m.nsite):
         rec[15, k, 0] = A["site_bodyid"][k]
         fv[15, k, 1:] = A["site_pos"][k]
@@ -229,7 +244,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray]) -> np.ndarray:
         rec[29, l, 1] = j
     for q in range(m.npair):
         g1, g2 = int(A["pair_geom1"][q]), int(A["pair_geom2"][q])
-        rec[30, q, :3] = [g1, g2, A["pair_kind"][q]]
+        rec[30, q, :3] = [slot_of[g1], slot_of[g2], A["pair_kind"][q]]
         fv[30, q, 3] = topo["pair_incl"][q]
         fv[31, q] = [*A["geom_size"][g1], topo["pair_tw"][q]]
         fv[32, q, :3] = A["geom_size"][g2]

@@ -117,3 +117,23 @@ def test_lane_records_restate_the_model_tables(cube_model):
     enum = re.search(r"enum LaneQuad \{(.*?)\};", src, re.S).group(1)
     names = [t.strip().split("=")[0].strip() for t in enum.replace("\n", " ").split(",") if t.strip()]
     assert names[-1] == "LQ_COUNT" and len(names) - 1 == LANE_QUADS
+
+
+def test_geom_slots_and_pair_records(go2_model, cube_model):
+    """model.geom_slots: the Go2 feet-only model keeps frames for the five geoms of its contact pairs only (floor + four feet of
+    39), the Airbot models for every geom; the lane records' geom rows and pair rows go by slot."""
+    from rsr_mjx_amd.model import geom_slots, lane_records, topology_tables
+    sl = geom_slots(go2_model)
+    A = go2_model.arrays
+    assert len(sl) == 5 and sorted(set(A["pair_geom1"].tolist()) | set(A["pair_geom2"].tolist())) == sl.tolist()
+    rec = lane_records(go2_model, topology_tables(go2_model), sl)
+    fv = rec.view(np.float32)
+    for k, g in enumerate(sl):
+        assert rec[13, k, 0] == A["geom_bodyid"][g]
+        np.testing.assert_array_equal(fv[13, k, 1:], A["geom_pos"][g].astype(np.float32))
+        np.testing.assert_array_equal(fv[14, k], A["geom_quat"][g].astype(np.float32))
+    assert not rec[13:15, len(sl):].any()                                    # lanes past the slots read zeros
+    for q in range(go2_model.npair):
+        assert sl[rec[30, q, 0]] == A["pair_geom1"][q] and sl[rec[30, q, 1]] == A["pair_geom2"][q]
+        np.testing.assert_array_equal(fv[32, q, :3], A["geom_size"][A["pair_geom2"][q]].astype(np.float32))
+    np.testing.assert_array_equal(geom_slots(cube_model), np.arange(cube_model.ngeom))
