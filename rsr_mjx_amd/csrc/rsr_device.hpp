@@ -372,7 +372,8 @@ struct PhaseB {
 };
 template <class C>
 struct Smem {
-  static_assert(!C::TALIAS || (C::NB * 10 * 2 + C::NB * 6 >= C::NV * (C::NV + 1)), "phase A's dead arrays must hold the transpose scratch");
+  static_assert(C::NB * 10 * 2 + C::NB * 6 >= (C::ROWCHOL ? C::NCH * 22 : C::NV * (C::NV + 1)), "phase A's dead arrays must hold the transpose scratch");
+  static_assert(C::TALIAS || ((C::NBC * C::NCON > 16 ? 64 : 1) + C::NBASE + 4 + C::NCON * 8 + C::NEFC >= C::NV * (C::NV + 1)), "jtp | bval | wc | rw must hold the Hessian exchange");
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
   float fric[C::NGA * 3], mass[C::NB], damp[C::NV], floss[C::NV];
@@ -389,9 +390,15 @@ struct Smem {
   int xfrc_body, acc_body;
   float ginfo[C::NINFO > 0 ? C::NINFO : 1];            // env info block staged in LDS for the whole step (Go2)
   float com[C::NB * 3], cdof[C::NV * 6];               // needed again when the contact Jacobian is built
-  float M[C::NV * C::LD], T_store[C::TALIAS ? 1 : C::NV * C::LD];
-  __device__ __forceinline__ float* scratch_a() { if constexpr (C::TALIAS) return x.a.cinert; else return T_store; }   // phase A: mass-matrix factor transposes
-  __device__ __forceinline__ float* scratch_b() { if constexpr (C::TALIAS) return M; else return T_store; }            // Hessian exchange / transposes; env scratch
+  float M[C::NV * C::LD];
+  // The factorisations' transpose / exchange scratch (NV * LD floats) has no storage of its own:
+  //   scratch_a(): before the solve -- the mass-matrix factor's transposes -- phase A's arrays that are dead by then (cinert ..);
+  //   scratch_b(): from the Hessian on (block exchange, factor transposes) and for the env prologue / epilogue staging:
+  //                Dims::TALIAS: the mass matrix itself (single-iteration models: M is read for the last time when the Hessian
+  //                blocks are formed); otherwise the solver's own per-row scratch jtp | bval | wc | rw, none of which is live
+  //                across a factorisation (hessian_factor restores the zero words of bval that it overwrites).
+  __device__ __forceinline__ float* scratch_a() { return x.a.cinert; }
+  __device__ __forceinline__ float* scratch_b() { if constexpr (C::TALIAS) return M; else return jtp; }
   // contacts (active only)
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
   int cpair[C::NCON];
@@ -400,11 +407,12 @@ struct Smem {
   // dof of every friction / limit row (their Jacobian row is a single +-1 there) and the Hessian's diagonal accumulator
   int sdof[C::NSP + 1];
   float dgw[C::NV];
-  float jtp[C::NBC * C::NCON > 16 ? 64 : 1];           // J^T f: partial sums of the row groups (lane = group * NV + dof)
-  float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
-  float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float bmu[C::NBASE + 4];                             // per base row: friction coefficient of that direction
+  // (the next four are contiguous on purpose: scratch_b())
+  float jtp[C::NBC * C::NCON > 16 ? 64 : 1];           // J^T f: partial sums of the row groups (lane = group * NV + dof)
+  float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian (2*NBC-1 used)
+  float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
   union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
 

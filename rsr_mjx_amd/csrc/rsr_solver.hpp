@@ -306,6 +306,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     // operations in order, and the rows are in registers (waited for) before the factor loop that precedes the writes
     PROF(PS_H_XCHG)
     const float dinv = rowchol_factor<C, false>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
+    if constexpr (!C::TALIAS) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }      // the null row's value (the exchange ran over it)
     PROF(PS_H_CHOL)
     return dinv;
   } else {
@@ -315,6 +316,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   WSYNC();
   PROF(PS_H_XCHG)
   const float dinv = chol_factor<C>(a, lt, s.scratch_b(), lane);
+  if constexpr (!C::TALIAS) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }
   PROF(PS_H_CHOL)
   return dinv;
   }
