@@ -14,6 +14,7 @@ for w in $WL; do
   rm -rf $O/trace_$w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace_$w -o bench -- python3 $R/bench.py --workload $w --steps 300 --warmup 50 --sub-batches 0 --no-cpu-baseline > $P/round2_bench_${w}_under_rocprofv3.json 2> $O/trace_$w.err
   python3 $R/tools/rocpd_summary.py kernels $(db $O/trace_$w) $P/round2_kernel_stats_$w.csv
+  rm -rf $O/trace_$w                  # (raw rocprofv3 output is tens of MB per run: only the summaries travel back)
   echo "$w trace done"
   for pass in "inst SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
               "cyc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \
@@ -22,6 +23,7 @@ for w in $WL; do
     rm -rf $O/pmc_${tag}_$w
     timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/pmc_${tag}_$w -o pmc -- python3 $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --sub-batches 0 > $O/pmc_${tag}_$w.json 2> $O/pmc_${tag}_$w.err
     python3 $R/tools/rocpd_summary.py pmc $(db $O/pmc_${tag}_$w) $P/round2_pmc_${tag}_$w.csv
+    rm -rf $O/pmc_${tag}_$w
   done
   echo "$w pmc done"
 done
