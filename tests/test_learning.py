@@ -513,3 +513,49 @@ def test_checkpoint_keeps_the_critics_own_normaliser(tmp_path):
     save_params(str(tmp_path / "d.npz"), (na, a))
     with pytest.raises(KeyError):
         load_params(str(tmp_path / "d.npz"), (nb, b))
+
+
+def test_rsr_dataset_tables(tmp_path):
+    """learning.datasets.load_rsr_datasets: the five transition sets of reference test/rsr_policy_training.py:150-209, its
+    truncation rule and its error cases (missing file, too few rows, wrong width, empty file)."""
+    from rsr_mjx_amd.learning import datasets as D, pipeline
+    rng = np.random.default_rng(0)
+    T, od, ad = 12, 4, 2
+    tabs = {"real_obs.txt": rng.normal(size=(T + 1, od)), "real_action.txt": rng.normal(size=(T, ad)),
+            "past_sim_obs.txt": rng.normal(size=(T + 3, od)), "current_sim_obs.txt": rng.normal(size=(T + 1, od)),
+            "obs.txt": rng.normal(size=(T + 1, od)), "actions.txt": rng.normal(size=(T, ad))}
+    def write(d, t):
+        d.mkdir(exist_ok=True)
+        for k, v in t.items():
+            np.savetxt(d / k, v, delimiter=",")
+        return d
+    d = write(tmp_path / "a", tabs)
+    s, a, nr, nps, ncs = D.load_rsr_datasets(d, max_transitions=50)
+    assert s.shape == (T, od) and a.shape == (T, ad)
+    np.testing.assert_allclose(s, tabs["real_obs.txt"][:T]); np.testing.assert_allclose(nr, tabs["real_obs.txt"][1:T + 1])
+    np.testing.assert_allclose(nps, tabs["past_sim_obs.txt"][1:T + 1]); np.testing.assert_allclose(ncs, tabs["current_sim_obs.txt"][1:T + 1])
+    s5 = D.load_rsr_datasets(d, max_transitions=5)
+    assert all(x.shape[0] == 5 for x in s5)
+    np.testing.assert_allclose(s5[4], tabs["current_sim_obs.txt"][1:6])
+    # what the loader returns is what the pipeline consumes
+    data = pipeline.build_policy_rsr_data(*s5, num_samples=6, device="cpu")
+    assert data.reference_data.shape == (5, 2 * od + ad) and data.grid.shape == (6, 2 * od + ad)
+    # a one-line file is one row
+    np.savetxt(tmp_path / "one.txt", np.arange(3.0)[None], delimiter=",")
+    assert D.load_table(tmp_path / "one.txt").shape == (1, 3)
+    # error cases
+    (d / "obs.txt").unlink()
+    with pytest.raises(FileNotFoundError, match="obs.txt"):
+        D.load_rsr_datasets(d)
+    short = dict(tabs); short["current_sim_obs.txt"] = tabs["current_sim_obs.txt"][:T]
+    with pytest.raises(ValueError, match="current_sim_obs.txt needs at least 13 rows"):
+        D.load_rsr_datasets(write(tmp_path / "b", short))
+    wide = dict(tabs); wide["actions.txt"] = rng.normal(size=(T, ad + 1))
+    with pytest.raises(ValueError, match="actions.txt must have 2 action features"):
+        D.load_rsr_datasets(write(tmp_path / "c", wide))
+    few = dict(tabs); few["real_obs.txt"] = tabs["real_obs.txt"][:1]
+    with pytest.raises(ValueError, match="Not enough aligned transitions"):
+        D.load_rsr_datasets(write(tmp_path / "e", few))
+    e = write(tmp_path / "f", tabs); (e / "real_obs.txt").write_text("")
+    with pytest.raises(ValueError, match="real_obs.txt is empty"):
+        D.load_rsr_datasets(e)
