@@ -168,22 +168,65 @@ __device__ void go2_sensors(const DModel& m, const Smem<C>& s, G2Sens& o) {
   o.glin[0] = v.x; o.glin[1] = v.y; o.glin[2] = v.z; o.gang[0] = w.x; o.gang[1] = w.y; o.gang[2] = w.z;
 }
 
-// joystick.py:284-340: 48-dim "state" obs into obs_lds; advances ginfo rng by five splits (wave-cooperative)
+// jax.random.split(key, N) in registers: the 2N output words are threefry(key, (j, N + j)) of lanes j < N -- word t is the first
+// output of lane t for t < N and the second output of lane t - N otherwise -- fetched with v_readlane: no LDS, no barrier.
+template <int N>
+__device__ __forceinline__ void tf_split_reg(uint32_t k0, uint32_t k1, int lane, uint32_t (&out)[N][2]) {
+  uint32_t o0, o1;
+  threefry2x32(k0, k1, (uint32_t)lane, (uint32_t)(N + lane), o0, o1);
+#pragma unroll
+  for (int r = 0; r < N; ++r)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int t = 2 * r + w;
+      out[r][w] = (uint32_t)(t < N ? rdlane_i((int)o0, t) : rdlane_i((int)o1, t - N));
+    }
+}
+// One lane's share of a batch of jax.random.uniform draws evaluated together: this lane is word pair `idx` of a draw of n
+// elements with key (k0, k1), whose bits go to bits[off .. off + n) (same split-halves layout as random_bits).
+__device__ __forceinline__ void tf_bits_batched(uint32_t k0, uint32_t k1, int n, int idx, int off, bool on, uint32_t* bits) {
+  const int half = (n + 1) / 2;
+  const bool two = half + idx < n;
+  uint32_t o0, o1;
+  threefry2x32(k0, k1, (uint32_t)idx, two ? (uint32_t)(half + idx) : 0u, o0, o1);
+  if (on) { bits[off + idx] = o0; if (two) bits[off + half + idx] = o1; }
+}
+
+// joystick.py:284-340: 48-dim "state" obs into obs_lds; advances ginfo rng by five splits.  The five splits are a serial
+// chain of register-only evaluations; the five draws (3, 3, 3, 12, 12 elements) are then one evaluation with a lane per
+// word pair and one barrier (ten evaluations with two barriers each when every split and draw went through LDS).
 template <class C>
 __device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane) {
 #pragma clang fp contract(off)
   const float* F = m.env_go2f;
   const bool idel = m.env_go2i[1] > 0;
   uint32_t rng0 = __float_as_uint(s.ginfo[G2_RNG]), rng1 = __float_as_uint(s.ginfo[G2_RNG + 1]);
-  uint32_t ks[2][2];
+  rng0 = (uint32_t)uniform_i((int)rng0); rng1 = (uint32_t)uniform_i((int)rng1);
   const float level = F[2];
   // order of the draws: gyro, gravity, linvel, joint angles, joint velocities
+  uint32_t dk[5][2];
+#pragma unroll
   for (int d = 0; d < 5; ++d) {
-    tf_split<2>(rng0, rng1, bits, lane, ks);
-    rng0 = ks[0][0]; rng1 = ks[0][1];
-    const int n = d < 3 ? 3 : 12;
-    float u = tf_uniform(ks[1][0], ks[1][1], n, 0.0f, 1.0f, bits, lane);
+    uint32_t ks[2][2];
+    tf_split_reg<2>(rng0, rng1, lane, ks);
+    rng0 = ks[0][0]; rng1 = ks[0][1]; dk[d][0] = ks[1][0]; dk[d][1] = ks[1][1];
+  }
+  {
+    // lanes [0,2) [2,4) [4,6): the three 3-element draws; [6,12) [12,18): the two 12-element draws
+    const int d = lane < 6 ? (lane >> 1) : (lane < 12 ? 3 : 4);
+    const int idx = lane < 6 ? (lane & 1) : (lane < 12 ? lane - 6 : lane - 12);
+    uint32_t k0 = dk[4][0], k1 = dk[4][1];
+#pragma unroll
+    for (int q = 3; q >= 0; --q) if (d == q) { k0 = dk[q][0]; k1 = dk[q][1]; }
+    WSYNC();
+    tf_bits_batched(k0, k1, d < 3 ? 3 : 12, idx, d < 3 ? 3 * d : (d == 3 ? 9 : 21), lane < 18, bits);
+    WSYNC();
+  }
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const int n = d < 3 ? 3 : 12, off = d < 3 ? 3 * d : (d == 3 ? 9 : 21);
     if (lane < n) {
+      const float u = uniform_from_bits(bits[off + lane], 0.0f, 1.0f);
       float src, scale; int dst;
       if (d == 0) { src = idel ? s.ginfo[G2_GYRO_BUF + lane] : sn.gyro[lane]; scale = F[5]; dst = 3 + lane; }
       else if (d == 1) { src = idel ? s.ginfo[G2_GRAV_BUF + lane] : sn.gravity[lane]; scale = F[6]; dst = 6 + lane; }
@@ -921,13 +964,25 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   {
     uint32_t rng0 = __float_as_uint(s.ginfo[G2_RNG]), rng1 = __float_as_uint(s.ginfo[G2_RNG + 1]);
     uint32_t k3[3][2], k4[4][2];
-    tf_split<3>(rng0, rng1, bits, lane, k3);
-    tf_split<4>(k3[1][0], k3[1][1], bits, lane, k4);          // sample_command: rng, y_rng, w_rng, z_rng
+    rng0 = (uint32_t)uniform_i((int)rng0); rng1 = (uint32_t)uniform_i((int)rng1);
+    tf_split_reg<3>(rng0, rng1, lane, k3);
+    tf_split_reg<4>(k3[1][0], k3[1][1], lane, k4);          // sample_command: rng, y_rng, w_rng, z_rng
     float amp = lane < 3 ? F[10 + lane] : 0.0f;
-    float y = tf_uniform(k4[1][0], k4[1][1], 3, -amp, amp, bits, lane);
-    float uz = tf_uniform(k4[3][0], k4[3][1], 3, 0.0f, 1.0f, bits, lane);
-    float uw = tf_uniform(k4[2][0], k4[2][1], 3, 0.0f, 1.0f, bits, lane);
-    float uu = rdlane(tf_uniform(k3[2][0], k3[2][1], 1, 0.0f, 1.0f, bits, lane), 0);
+    {
+      // the four draws in one evaluation: lanes [0,2) y, [2,4) z, [4,6) w (3 elements each), lane 6 the resampling time (1)
+      const int d = lane < 6 ? (lane >> 1) : 3;
+      uint32_t k0 = k3[2][0], k1 = k3[2][1];
+      if (d == 0) { k0 = k4[1][0]; k1 = k4[1][1]; }
+      if (d == 1) { k0 = k4[3][0]; k1 = k4[3][1]; }
+      if (d == 2) { k0 = k4[2][0]; k1 = k4[2][1]; }
+      WSYNC();
+      tf_bits_batched(k0, k1, d < 3 ? 3 : 1, lane < 6 ? (lane & 1) : 0, 3 * d, lane < 7, bits);
+      WSYNC();
+    }
+    const float y = lane < 3 ? uniform_from_bits(bits[lane], -amp, amp) : 0.0f;
+    const float uz = lane < 3 ? uniform_from_bits(bits[3 + lane], 0.0f, 1.0f) : 0.0f;
+    const float uw = lane < 3 ? uniform_from_bits(bits[6 + lane], 0.0f, 1.0f) : 0.0f;
+    const float uu = uniform_from_bits(bits[9], 0.0f, 1.0f);
     WSYNC();
     if (lane < 3 && steps_cmd <= 0.0f) {
 #pragma clang fp contract(off)
