@@ -326,7 +326,8 @@ __device__ __forceinline__ void prof_timeline(float* d, unsigned long long rt0, 
 // ---- diagnostic build only (-DRSR_PROFILE): per-stage cycle counters, written to the debug buffer ----
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
-       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_L_PREP, PS_L_P0, PS_L_LO, PS_L_ITER, PS_U_JTF, PS_S_COST, PS_S_JTF, PS_COUNT };
+       PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_L_PREP, PS_L_P0, PS_L_LO, PS_L_ITER, PS_U_JTF, PS_S_COST, PS_S_JTF,
+       PS_K_LOAD, PS_K_LOCAL, PS_K_TREE, PS_K_STORE, PS_C_LOAD, PS_C_COM, PS_C_CINERT, PS_C_CRB, PS_F_LOAD, PS_F_VEL, PS_F_FRC, PS_F_SUM, PS_COUNT };
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
@@ -339,16 +340,19 @@ __device__ __forceinline__ unsigned long long prof_now() {
 #define PROF_ARG , Prof& prof_
 #define PROF_PASS , prof_
 #define PROF(stage) { unsigned long long t_ = prof_now(); prof_.acc[stage] += t_ - prof_.t0; prof_.t0 = t_; }
+#define PROF_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #elif defined(RSR_TIMELINE)      // start / end stamps only: the wave timeline without the per-stage stamps' overhead
 #define PROF_DECL const unsigned long long prof_rt0_ = prof_realtime(); unsigned long long prof_ct0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_ct0_)::"memory");
 #define PROF_ARG
 #define PROF_PASS
 #define PROF(stage)
+#define PROF_VMWAIT()
 #else
 #define PROF_DECL
 #define PROF_ARG
 #define PROF_PASS
 #define PROF(stage)
+#define PROF_VMWAIT()
 #endif
 
 // ---- LDS image of one environment ----
@@ -467,7 +471,7 @@ __device__ __forceinline__ Q4 q4_of(int4 r) { return Q4{asf(r.x), asf(r.y), asf(
 // register-only steps instead of nbody LDS round trips.  Bodies carry at most one joint (checked on the host).
 // =====================================================================================
 template <class C>
-__device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C>& s, int lane) {
+__device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C>& s, int lane PROF_ARG) {
   const int lr = lrec_lane(lane);
   static_assert(C::NB <= 64 && C::NG <= 64 && C::NJ <= 64 && C::NS <= 64, "one lane per body / geom / joint / site");
   // every model constant of the stage, for all of this lane's roles
@@ -478,6 +482,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
   const int4 rj_posax = lrec<C>(h, LQ_J_POSAX, lr), rj_ax = lrec<C>(h, LQ_J_AX, lr);
   const int4 rg_pos = lrec<C>(h, LQ_G_POS, lr), rg_quat = lrec<C>(h, LQ_G_QUAT, lr);
   const int4 rs_pos = lrec<C>(h, LQ_S_POS, lr), rs_quat = lrec<C>(h, LQ_S_QUAT, lr);
+  PROF_VMWAIT(); PROF(PS_K_LOAD)
   const int b = lane < C::NB ? lane : 0;
   const int parent = rb_ids.x, depth = lane < C::NB ? rb_ids.y : -1;
   V3 bp = v3_xyz(rb_pos);
@@ -509,6 +514,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
       }
     }
   }
+  PROF(PS_K_LOCAL)
   // compose down the tree: after level d every body of depth <= d holds its world pose
   V3 pos = lane == 0 ? v3(0, 0, 0) : lp;
   Q4 q = lane == 0 ? Q4{1, 0, 0, 0} : lq;
@@ -517,6 +523,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
     Q4 pq = Q4{__shfl(q.w, parent), __shfl(q.x, parent), __shfl(q.y, parent), __shfl(q.z, parent)};
     if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
   }
+  PROF(PS_K_TREE)
   if (lane < C::NB) {
     st3(&s.xpos[3 * b], pos); st4(&s.xquat[4 * b], q);
     M33 R = q2m(q);
@@ -530,6 +537,7 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
     for (int c = 0; c < 9; ++c) s.x.a.ximat[9 * b + c] = Ri.m[c];
   }
   WSYNC();
+  PROF(PS_K_STORE)
   if (lane < C::NJ) {          // joint anchors / axes in the world frame (frame of the body before the joint acts)
     const int j = lane, jb = rj_ids.x, jpar = rj_ids.y;
     if (rj_ids.z == JNT_FREE) {
@@ -643,10 +651,11 @@ __device__ __forceinline__ void chain_sum_quad(const Smem<C>& s, const float* ve
 // stage 2+3: com_pos, crb, dense mass matrix (MJX smooth.com_pos / crb / make_m)
 // =====================================================================================
 template <class C>
-__device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem<C>& s, int lane) {
+__device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem<C>& s, int lane PROF_ARG) {
   const int lr = lrec_lane(lane);
   const int4 rb_misc = lrec<C>(h, LQ_B_MISC, lr), rb_inertia = lrec<C>(h, LQ_B_INERTIA, lr);
   const int4 rd_ids = lrec<C>(h, LQ_D_IDS, lr), rd_masks = lrec<C>(h, LQ_D_MASKS, lr);
+  PROF_VMWAIT(); PROF(PS_C_LOAD)
   const int max_sub = h.max_sub, max_chain = h.max_chain;
   // subtree mask of body lane / 4 for the four-lanes-per-body composite inertia sum below (body b's mask sits in lane b's
   // record; a cross-lane read needs its source lane active, so it is fetched here in uniform code)
@@ -681,6 +690,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem
     }
   }
   WSYNC();
+  PROF(PS_C_COM)
   if (lane < C::NB) {
     int b = lane;
     const float* R = &s.x.a.ximat[9 * b];
@@ -709,9 +719,11 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem
   }
   for (int t = lane; t < C::NV * C::LD; t += 64) s.M[t] = 0.0f;
   WSYNC();
+  PROF(PS_C_CINERT)
   // composite inertia of body b = sum of cinert over its subtree (the world's is not needed: zero)
   subtree_sum_quad<C, 10>(s.x.a.cinert, s.x.a.crb, (qb == 0 || qb >= C::NB) ? 0u : crb_mask_q, lane);
   WSYNC();
+  PROF(PS_C_CRB)
   if (lane < C::NV) {
     int i = lane;
     float f[6];
@@ -1391,10 +1403,11 @@ __device__ __forceinline__ void motion_cross(float* o, const float* u, const flo
 
 struct Q6 { float qd; float c[6]; };      // one chain dof: its velocity and a spatial vector
 template <class C>
-__device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Smem<C>& s, int lane, float qvel_i, float ctrl_u) {
+__device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Smem<C>& s, int lane, float qvel_i, float ctrl_u PROF_ARG) {
   const int lr = lrec_lane(lane);
   const int4 rb_misc = lrec<C>(h, LQ_B_MISC, lr), rd_ids = lrec<C>(h, LQ_D_IDS, lr), rd_masks = lrec<C>(h, LQ_D_MASKS, lr);
   const int4 rd_act = lrec<C>(h, LQ_D_ACT, lr), rd_ctrl = lrec<C>(h, LQ_D_CTRL, lr), rd_bias = lrec<C>(h, LQ_D_BIAS, lr), rd_frc = lrec<C>(h, LQ_D_FRC, lr);
+  PROF_VMWAIT(); PROF(PS_F_LOAD)
   const int max_sub = h.max_sub, max_chain = h.max_chain;
   const float grav0 = h.grav0, grav1 = h.grav1, grav2 = h.grav2;
   const int qb = lane >> 2;            // four lanes per body for the subtree force sums below (see com_crb_mass)
@@ -1436,6 +1449,7 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Sm
     for (int c = 0; c < 6; ++c) s.x.a.cdofdot[6 * lane + c] = free_trans ? 0.0f : o[c];
   }
   WSYNC();
+  PROF(PS_F_VEL)
   // object velocity at every site, world frame (source of gyro / velocimeter / framelinvel / frameangvel sensors)
   if (lane < C::NS) {
     const int sb = site_b;
@@ -1464,8 +1478,10 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Sm
     s.x.a.cfrc[6 * qb + 3] = f1[3] + tl.x; s.x.a.cfrc[6 * qb + 4] = f1[4] + tl.y; s.x.a.cfrc[6 * qb + 5] = f1[5] + tl.z;
   }
   WSYNC();
+  PROF(PS_F_FRC)
   subtree_sum_quad<C, 6>(s.x.a.cfrc, s.x.a.cfrcsum, qb >= C::NB ? 0u : frc_mask_q, lane);
   WSYNC();
+  PROF(PS_F_SUM)
   float smooth = 0.0f;
   if (lane < C::NV) {
     int i = lane, b = rd_ids.y;

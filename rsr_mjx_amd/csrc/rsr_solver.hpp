@@ -542,15 +542,15 @@ struct FwdOut { float qacc, qfc, fsmooth; int nefc; SolveStats st; };
 template <class C>
 __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& s, int lane, float (&Mrow)[C::NV], float& warm, FwdOut<C>& out,
                         float* dbg PROF_ARG) {
-  kinematics<C>(m, h, s, lane);
+  kinematics<C>(m, h, s, lane PROF_PASS);
   PROF(PS_KIN)
-  com_crb_mass<C>(m, h, s, lane);
+  com_crb_mass<C>(m, h, s, lane PROF_PASS);
 #pragma unroll
   for (int j = 0; j < C::NV; ++j) Mrow[j] = s.M[(lane < C::NV ? lane : 0) * C::LD + j];   // lanes >= NV: row 0, every use is masked
   PROF(PS_COMCRB)
   // velocity stage first: its scratch and the frames die before the Jacobian claims the shared LDS region
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
-  float fs = smooth_forces<C>(m, h, s, lane, qvel_i, 0.0f);
+  float fs = smooth_forces<C>(m, h, s, lane, qvel_i, 0.0f PROF_PASS);
   PROF(PS_SMOOTH)
   // qacc_smooth = M^-1 qfrc_smooth
   float a[C::NCH], lt[C::NCH];
