@@ -327,7 +327,8 @@ __device__ __forceinline__ void prof_timeline(float* d, unsigned long long rt0, 
 #ifdef RSR_PROFILE
 enum { PS_LOAD = 0, PS_KIN, PS_COMCRB, PS_COLL, PS_ROWS, PS_SMOOTH, PS_CHOLM, PS_SOLVE_INIT, PS_HESS, PS_LS, PS_UPD,
        PS_INTEG, PS_EPILOGUE, PS_H_PREP, PS_H_SPARSE, PS_H_CONTACT, PS_H_XCHG, PS_H_CHOL, PS_LS_SETUP, PS_X0, PS_X1, PS_X2, PS_X3, PS_X4, PS_X5, PS_X6, PS_X7, PS_L_PREP, PS_L_P0, PS_L_LO, PS_L_ITER, PS_U_JTF, PS_S_COST, PS_S_JTF,
-       PS_K_LOAD, PS_K_LOCAL, PS_K_TREE, PS_K_STORE, PS_C_LOAD, PS_C_COM, PS_C_CINERT, PS_C_CRB, PS_F_LOAD, PS_F_VEL, PS_F_FRC, PS_F_SUM, PS_COUNT };
+       PS_K_LOAD, PS_K_LOCAL, PS_K_TREE, PS_K_STORE, PS_C_LOAD, PS_C_COM, PS_C_CINERT, PS_C_CRB, PS_F_LOAD, PS_F_VEL, PS_F_FRC, PS_F_SUM,
+       PS_E_SENS, PS_E_FIFO, PS_E_FEET, PS_E_OBS, PS_E_PRIV, PS_E_REWARD, PS_E_BOOK, PS_COUNT };
 struct Prof { unsigned long long t0; unsigned long long acc[PS_COUNT]; };
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;

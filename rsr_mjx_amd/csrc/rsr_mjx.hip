@@ -196,7 +196,7 @@ __device__ __forceinline__ void tf_bits_batched(uint32_t k0, uint32_t k1, int n,
 // chain of register-only evaluations; the five draws (3, 3, 3, 12, 12 elements) are then one evaluation with a lane per
 // word pair and one barrier (ten evaluations with two barriers each when every split and draw went through LDS).
 template <class C>
-__device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane) {
+__device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane, float home_l) {
 #pragma clang fp contract(off)
   const float* F = m.env_go2f;
   const bool idel = m.env_go2i[1] > 0;
@@ -235,7 +235,7 @@ __device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* ob
       else { src = s.qvel[6 + lane]; scale = F[4]; dst = 21 + lane; }
       float a = 2.0f * u; float b = a - 1.0f; float c = b * level; float e = c * scale;
       float val = src + e;
-      if (d == 3) val = val - m.env_go2_home[7 + lane];
+      if (d == 3) val = val - home_l;             // home_l = env_go2_home[7 + lane] (lanes < 12), loaded by the caller ahead of time
       obs_lds[dst] = val;
     }
   }
@@ -285,6 +285,43 @@ __device__ float go2_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& 
   if (t < 71) return s.ginfo[G2_AIR + t - 67];
   if (t < 74) return s.ginfo[G2_XFRC + t - 71];
   return s.ginfo[G2_SINCE_PERT] >= s.ginfo[G2_STEPS_PERT] ? 1.0f : 0.0f;
+}
+
+// The same element fetched as a gather: every element but the 15 sensor values (registers) and the kick flag is one LDS
+// word, so the lanes compute an address with selects and issue ONE load (go2_priv_elem walks fifteen divergent branches,
+// each waiting for its own load).  FIRST: t < 64 (the only elements that can be sensor values).  foot_site: env_ids[1..4].
+template <class C, bool FIRST>
+__device__ __forceinline__ float go2_priv_gather(const DModel& m, const Smem<C>& s, const G2Sens& sn, const float* obs_lds, int t,
+                                                 const int (&foot_site)[4], float kick_flag, float home_l) {
+#pragma clang fp contract(off)
+  const int k = t - 48;
+  const float* p = obs_lds + (t < 48 ? t : 0);
+  p = (k >= 15 && k < 27) ? &s.qpos[7 + (k - 15)] : p;
+  p = (k >= 27 && k < 39) ? &s.qvel[6 + (k - 27)] : p;
+  p = (k >= 39 && k < 51) ? &s.aforce[k - 39] : p;
+  p = (k >= 51 && k < 55) ? &s.ginfo[G2_LAST_CONTACT + (k - 51)] : p;
+  {
+    const int kk = k - 55, ft = kk / 3;
+    const int site = ft == 0 ? foot_site[0] : ft == 1 ? foot_site[1] : ft == 2 ? foot_site[2] : foot_site[3];
+    p = (k >= 55 && k < 67) ? &s.slinvel[3 * site + (kk - 3 * ft)] : p;
+  }
+  p = (k >= 67 && k < 71) ? &s.ginfo[G2_AIR + (k - 67)] : p;
+  p = (k >= 71 && k < 74) ? &s.ginfo[G2_XFRC + (k - 71)] : p;
+  const int hk = k - 15 < 0 ? 0 : (k - 15 > 11 ? 11 : k - 15);
+  const float h = __shfl(home_l, hk);            // lane j holds home[7 + j]
+  float v = *p;
+  if (k >= 15 && k < 27) v = v - h;
+  if constexpr (FIRST) {
+    float sv = sn.gyro[0];
+    sv = k == 1 ? sn.gyro[1] : sv; sv = k == 2 ? sn.gyro[2] : sv;
+    sv = k == 3 ? sn.accel[0] : sv; sv = k == 4 ? sn.accel[1] : sv; sv = k == 5 ? sn.accel[2] : sv;
+    sv = k == 6 ? sn.gravity[0] : sv; sv = k == 7 ? sn.gravity[1] : sv; sv = k == 8 ? sn.gravity[2] : sv;
+    sv = k == 9 ? sn.linvel[0] : sv; sv = k == 10 ? sn.linvel[1] : sv; sv = k == 11 ? sn.linvel[2] : sv;
+    sv = k == 12 ? sn.gang[0] : sv; sv = k == 13 ? sn.gang[1] : sv; sv = k == 14 ? sn.gang[2] : sv;
+    if (k >= 0 && k < 15) v = sv;
+  }
+  if (k == 74) v = kick_flag;
+  return v;
 }
 
 // ---------------------------------------------------------------- reset kernel
@@ -413,6 +450,8 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   const int units = sc.units, total = units * a.n;
   int* const ticket = sc.ticket + (sc.launch_id & 1u);
   for (;;) {                                                   // persistent wave: one work unit (env, phase) per trip
+  // (Drawing the next unit's ticket at the start of the current one hides the atomic's round trip but binds the last units of a
+  // launch to waves that are still busy while others idle: measured -3.4 % on the cube.)
   int tk = 0;
   if (lane == 0) {
     tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -719,7 +758,7 @@ __global__ __launch_bounds__(64) void go2_reset_kernel(const DModel* __restrict_
   G2Sens sn;
   go2_sensors<C>(m, s, sn);
   go2_accelerometer<C>(m, s, lane, f.qacc, sn);
-  go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  go2_obs<C>(m, s, sn, obs_lds, bits, lane, m.env_go2_home[7 + (lane < 12 ? lane : 0)]);
   for (int t = lane; t < GO2_PRIV; t += 64) { float v = go2_priv_elem<C>(m, s, sn, obs_lds, t); rec[L.priv_obs + t] = v; rec[L.f_priv_obs + t] = v; }
   store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
   for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];
@@ -844,10 +883,25 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
     time += hot.timestep;
   }
+  // per-joint constants of the epilogue (home pose, soft limits): vector loads take a couple of thousand cycles under load, so
+  // they are issued here and consumed after the sensor / FIFO / contact code
+  const int jl = lrec_lane(lane < 12 ? lane : 0);      // opaque: not merged with the prologue's load of the same address, which
+                                                        // would keep the value live (or spilled) across the whole substep loop
+  const float home_l = m.env_go2_home[7 + jl], soft_lo = m.env_go2_soft[jl], soft_hi = m.env_go2_soft[12 + jl];
+  // (the Episode wrapper's running sums and the feet of the contact pairs likewise)
+  int foot_of_pair = -1;                    // lane p < NP: the foot whose geom pair p holds (pairs are static), or -1
+  if (lane < C::NP) {
+    const int g1 = m.pair_geom1[lane], g2 = m.pair_geom2[lane], fl = m.env_ids[5];
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) { const int gf = m.env_ids[6 + fi]; if ((g2 == gf && g1 == fl) || (g1 == gf && g2 == fl)) foot_of_pair = fi; }
+  }
+  const float prev_done = wrap_episode ? rec[L.episode_done] : 0.0f;
+  const float em_old = (wrap_episode && lane < C::NMET + 2) ? rec[L.episode_metrics + lane] : 0.0f;
   // ---- sensors of the last forward pass, IMU FIFOs (:220-235) ----
   G2Sens sn;
   go2_sensors<C>(m, s, sn);
   go2_accelerometer<C>(m, s, lane, f.qacc, sn);
+  PROF(PS_E_SENS)
   const int idel = m.env_go2i[1];
   if (idel > 0) {
     float v = 0.0f;
@@ -860,35 +914,67 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     if (lane < 3) { s.ginfo[G2_GYRO_BUF + nb + lane] = sn.gyro[lane]; s.ginfo[G2_LINVEL_BUF + nb + lane] = sn.linvel[lane]; s.ginfo[G2_GRAV_BUF + nb + lane] = sn.gravity[lane]; }
     WSYNC();
   }
+  PROF(PS_E_FIFO)
   // ---- foot contacts (:236-245) ----
-  int contact[4] = {0, 0, 0, 0};
-  for (int i = 0; i < s.ncon; ++i) {
-    if (!(s.cdist[i] < 0.0f)) continue;
-    int g2 = m.pair_geom2[s.cpair[i]], g1 = m.pair_geom1[s.cpair[i]];
-    for (int fi = 0; fi < 4; ++fi) if ((g2 == m.env_ids[6 + fi] && g1 == m.env_ids[5]) || (g1 == m.env_ids[6 + fi] && g2 == m.env_ids[5])) contact[fi] = 1;
+  // lane p < NP knows which foot pair p belongs to (the pairs are static); lane i < ncon looks its contact's pair up there
+  int contact[4];
+  int foot_site[4];
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi) foot_site[fi] = m.env_ids[1 + fi];
+  {
+    const int nc = s.ncon, ci = lane < nc ? lane : 0;
+    const int cp = s.cpair[ci]; const float cd = s.cdist[ci];
+    const int fo = __shfl(foot_of_pair, cp & 63);
+    const int my_foot = (lane < nc && cd < 0.0f) ? fo : -1;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) contact[fi] = __ballot(my_foot == fi) != 0ull ? 1 : 0;
   }
   int first_contact[4]; float feet_z[4];
   for (int fi = 0; fi < 4; ++fi) {
     bool filt = contact[fi] || s.ginfo[G2_LAST_CONTACT + fi] != 0.0f;
     first_contact[fi] = (s.ginfo[G2_AIR + fi] > 0.0f) && filt;
-    feet_z[fi] = s.spos[3 * m.env_ids[1 + fi] + 2];
+    feet_z[fi] = s.spos[3 * foot_site[fi] + 2];
   }
   WSYNC();
   if (lane < 4) {
     s.ginfo[G2_AIR + lane] += dt;
-    s.ginfo[G2_SWING + lane] = fmaxf(s.ginfo[G2_SWING + lane], s.spos[3 * m.env_ids[1 + lane] + 2]);
+    s.ginfo[G2_SWING + lane] = fmaxf(s.ginfo[G2_SWING + lane], s.spos[3 * (lane == 0 ? foot_site[0] : lane == 1 ? foot_site[1] : lane == 2 ? foot_site[2] : foot_site[3]) + 2]);
   }
   WSYNC();
-  go2_obs<C>(m, s, sn, obs_lds, bits, lane);
+  PROF(PS_E_FEET)
+  go2_obs<C>(m, s, sn, obs_lds, bits, lane, home_l);
+  PROF(PS_E_OBS)
   float priv[2];                                              // this lane's elements of privileged_state (info as of now)
-  priv[0] = go2_priv_elem<C>(m, s, sn, obs_lds, lane);
-  priv[1] = lane + 64 < GO2_PRIV ? go2_priv_elem<C>(m, s, sn, obs_lds, lane + 64) : 0.0f;
+  {
+    const float kick_flag = s.ginfo[G2_SINCE_PERT] >= s.ginfo[G2_STEPS_PERT] ? 1.0f : 0.0f;
+    priv[0] = go2_priv_gather<C, true>(m, s, sn, obs_lds, lane, foot_site, kick_flag, home_l);
+    priv[1] = go2_priv_gather<C, false>(m, s, sn, obs_lds, lane + 64 < GO2_PRIV ? lane + 64 : GO2_PRIV - 1, foot_site, kick_flag, home_l);
+  }
   float done = sn.up[2] < 0.0f ? 1.0f : 0.0f;
-  // ---- rewards (:367-593): scalar algebra on lane 0, evaluated op by op ----
+  PROF(PS_E_PRIV)
+  // ---- rewards (:367-593): the per-joint pieces of the seven 12-term sums are computed by lanes 0..11 and staged; lane 0 adds
+  // them up in the reference's order and evaluates the rest of the scalar algebra op by op ----
+  float* rstage = s.scratch_b() + 160;                        // [7][12]
+  if (lane < 12) {
+#pragma clang fp contract(off)
+    const float q = s.qpos[7 + lane], dq = q - home_l;
+    const float lo_ = q - soft_lo, hi_ = q - soft_hi;
+    const float w = (lane % 3 == 2) ? 0.1f : 1.0f;
+    const float t = s.aforce[lane];
+    const float dd = act_in - s.ginfo[G2_LAST_ACT + lane];
+    rstage[lane] = fabsf(dq);
+    rstage[12 + lane] = -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
+    rstage[24 + lane] = dq * dq * w;
+    rstage[36 + lane] = t * t;
+    rstage[48 + lane] = fabsf(t);
+    rstage[60 + lane] = fabsf(s.qvel[6 + lane]) * fabsf(t);
+    rstage[72 + lane] = dd * dd;
+  }
+  WSYNC();
   float reward = 0.0f;
   if (lane == 0) {
 #pragma clang fp contract(off)
-    const float* SC = m.env_go2_scales; const float* home = m.env_go2_home;
+    const float* SC = m.env_go2_scales;
     const float* cmd = &s.ginfo[G2_CMD];
     float cmd_norm = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
     float moving = cmd_norm > 0.01f ? 1.0f : 0.0f, still = cmd_norm < 0.01f ? 1.0f : 0.0f;
@@ -903,30 +989,23 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     rw[RW_ANG_VEL_XY] = sn.gang[0] * sn.gang[0] + sn.gang[1] * sn.gang[1];
     rw[RW_ORIENT] = sn.up[0] * sn.up[0] + sn.up[1] * sn.up[1];
     {
-      float sa = 0, lim = 0, pose = 0;
-      for (int i = 0; i < 12; ++i) {
-        float q = s.qpos[7 + i], dq = q - home[7 + i];
-        sa += fabsf(dq);
-        float lo_ = q - m.env_go2_soft[i], hi_ = q - m.env_go2_soft[12 + i];
-        lim += -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
-        float w = (i % 3 == 2) ? 0.1f : 1.0f;
-        pose += dq * dq * w;
+      float sa = 0, lim = 0, pose = 0, s2 = 0, s1 = 0, en = 0, ar = 0;
+#pragma unroll 1
+      for (int i0 = 0; i0 < 12; i0 += 4) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) {
+          sa += rstage[i]; lim += rstage[12 + i]; pose += rstage[24 + i];
+          s2 += rstage[36 + i]; s1 += rstage[48 + i]; en += rstage[60 + i]; ar += rstage[72 + i];
+        }
       }
       rw[RW_STAND_STILL] = sa * still; rw[RW_DOF_LIMITS] = lim; rw[RW_POSE] = expf(-pose);
-    }
-    rw[RW_TERM] = done;
-    {
-      float s2 = 0, s1 = 0, en = 0, ar = 0;
-      for (int i = 0; i < 12; ++i) {
-        float t = s.aforce[i]; s2 += t * t; s1 += fabsf(t); en += fabsf(s.qvel[6 + i]) * fabsf(t);
-        float dd = a.action[(size_t)e * C::NU + i] - s.ginfo[G2_LAST_ACT + i]; ar += dd * dd;
-      }
+      rw[RW_TERM] = done;
       rw[RW_TORQUES] = sqrtf(s2) + s1; rw[RW_ENERGY] = en; rw[RW_ACTION_RATE] = ar;
     }
     {
       float slip = 0, clear = 0, height = 0, air = 0; int nair = 0;
       for (int fi = 0; fi < 4; ++fi) {
-        const int sid = m.env_ids[1 + fi];
+        const int sid = foot_site[fi];
         float vx = s.slinvel[3 * sid], vy = s.slinvel[3 * sid + 1];
         float v2 = vx * vx + vy * vy;
         slip += v2 * (float)contact[fi];
@@ -958,6 +1037,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
   reward = rdlane(reward, 0);
   WSYNC();
+  PROF(PS_E_REWARD)
   // ---- bookkeeping (:255-277): last actions, command resampling (threefry), timers ----
   if (lane < C::NU) { s.ginfo[G2_LAST_LAST_ACT + lane] = s.ginfo[G2_LAST_ACT + lane]; s.ginfo[G2_LAST_ACT + lane] = act_in; }
   float steps_cmd = s.ginfo[G2_STEPS_CMD] - 1.0f;
@@ -1011,27 +1091,35 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 #pragma clang fp contract(off)
     float swing_mean = (((s.ginfo[G2_SWING] + s.ginfo[G2_SWING + 1]) + s.ginfo[G2_SWING + 2]) + s.ginfo[G2_SWING + 3]) / 4.0f;
     rwl[RW_COUNT] = swing_mean;
-    for (int k = 0; k < C::NMET; ++k) rec[L.metrics + k] = rwl[k];
-    rec[L.reward] = reward;
-    if (wrap_episode) {
-      steps += 1.0f;
-      bool over = steps >= (float)m.episode_length;
-      rec[L.truncation] = over ? 1.0f - done : 0.0f;
-      float prev_done = rec[L.episode_done];
-      float* em = rec + L.episode_metrics;
-      em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
-      em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
-      for (int i = 0; i < C::NMET; ++i) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + rwl[i];
-      if (over) done = 1.0f;
-      rec[L.episode_done] = done;
-    }
-    rec[L.steps] = steps;
-    rec[L.done] = done;
-    int* st = reinterpret_cast<int*>(rec + L.stats);
-    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
   }
   WSYNC();
-  done = rdlane(done, 0);
+  {
+    // metrics and the Episode wrapper's sums: one lane per entry (rwl[0..NMET) = the scaled terms + swing_peak)
+    bool over = false;
+    float trunc = 0.0f;
+    if (wrap_episode) {
+      steps += 1.0f;
+      over = steps >= (float)m.episode_length;
+      trunc = over ? 1.0f - done : 0.0f;
+    }
+    if (lane < C::NMET) rec[L.metrics + lane] = rwl[lane];
+    if (wrap_episode && lane < C::NMET + 2) {
+      float* em = rec + L.episode_metrics;
+      const float add = lane == 0 ? reward : (lane == 1 ? 1.0f : rwl[lane >= 2 ? lane - 2 : 0]);
+      em[lane] = prev_done != 0.0f ? 0.0f : em_old + add;
+    }
+    if (over) done = 1.0f;
+    if (lane == 0) {
+      rec[L.reward] = reward;
+      if (wrap_episode) { rec[L.truncation] = trunc; rec[L.episode_done] = done; }
+      rec[L.steps] = steps;
+      rec[L.done] = done;
+      int* st = reinterpret_cast<int*>(rec + L.stats);
+      st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+    }
+  }
+  WSYNC();
+  PROF(PS_E_BOOK)
   if (wrap_autoreset && done != 0.0f && lane < 3) s.ginfo[G2_XFRC + lane] = 0.0f;     // xfrc_applied belongs to `data`: back to the first state's zeros
   WSYNC();
   for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];       // info is never reset by AutoReset

@@ -27,6 +27,8 @@ for w in $WL; do
   done
   echo "$w pmc done"
 done
+# the plain bench lines quote the PMC summaries of THIS run (bench.py binds them to the hash of the kernel sources)
+cp $P/round2_pmc_*.csv $R/profiles/
 cd $R
 for w in $WL; do timeout -k 10 200 python3 bench.py --workload $w --steps 300 --warmup 50 > $P/round2_bench_$w.json 2> $O/bench_$w.err; echo "$w bench done"; done
 ls $P

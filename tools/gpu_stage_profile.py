@@ -22,7 +22,9 @@ NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "
          "ls: prepare (row pieces)", "ls: point alpha=0", "ls: first Newton point", "ls: iterations", "-", "init: M.a, J.a, costs of both starts", "init: J^T f, gradient",
          "kin: record loads", "kin: local transforms (sincos)", "kin: tree composition", "kin: body stores + barrier",
          "crb: record loads", "crb: subtree com", "crb: cinert, cdof, M zero", "crb: composite inertia",
-         "smooth: record loads", "smooth: cvel, cdof_dot", "smooth: cacc, cfrc", "smooth: subtree force sum"]
+         "smooth: record loads", "smooth: cvel, cdof_dot", "smooth: cacc, cfrc", "smooth: subtree force sum",
+         "go2 epilogue: sensors, accelerometer", "go2 epilogue: IMU FIFOs", "go2 epilogue: foot contacts", "go2 epilogue: obs + noise draws",
+         "go2 epilogue: privileged obs", "go2 epilogue: reward terms", "go2 epilogue: bookkeeping, command draws (rest = stores)"]
 n = 8192
 if "--go2" in sys.argv:
     from rsr_mjx_amd.envs import go2
