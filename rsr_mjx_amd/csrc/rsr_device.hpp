@@ -134,7 +134,7 @@ struct StepArgs {
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
           int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false,
-          bool TALIAS_ = false, int NGA_ = NG_>
+          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false>
 struct Dims {
   // LDS diet of the single-iteration models (Go2: one Hessian per substep, explicit Euler): the transpose / exchange scratch T
   // has no storage of its own -- before the solve it is the dead part of phase A (cinert .. cfrcsum), from the Hessian on it
@@ -142,6 +142,13 @@ struct Dims {
   // friction are kept for the NGA geoms that appear in a contact pair only (slots; Go2: floor or height field + four feet of
   // 39 geoms).  Together 13.4 KB -> under 10 KB per env: a fourth wave per SIMD.
   static constexpr bool TALIAS = TALIAS_;
+  // TTAIL (Go2, instead of TALIAS): from the Hessian on the scratch is the tail of the phase union -- phase A is larger than the
+  // Jacobian of a model with few contacts, and the part of it that the Jacobian does not overwrite is dead all the same.  The
+  // mass matrix then stays in LDS through the solve and the integration, and a lane reads its row of M where it needs it
+  // instead of carrying it in NV registers from the mass-matrix stage to the integrator (at 128 VGPRs those registers were
+  // spilled: every M.v product re-read its row from scratch memory).
+  static constexpr bool TTAIL = TTAIL_;
+  static constexpr bool MROW_LDS = TTAIL_;
   static constexpr int NGA = NGA_;
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
@@ -378,7 +385,9 @@ struct PhaseB {
 template <class C>
 struct Smem {
   static_assert(C::NB * 10 * 2 + C::NB * 6 >= (C::ROWCHOL ? C::NCH * 22 : C::NV * (C::NV + 1)), "phase A's dead arrays must hold the transpose scratch");
-  static_assert(C::TALIAS || ((C::NBC * C::NCON > 16 ? 64 : 1) + C::NBASE + 4 + C::NCON * 8 + C::NEFC >= C::NV * (C::NV + 1)), "jtp | bval | wc | rw must hold the Hessian exchange");
+  static_assert(C::TALIAS || C::TTAIL || ((C::NBC * C::NCON > 16 ? 64 : 1) + C::NBASE + 4 + C::NCON * 8 + C::NEFC >= C::NV * (C::NV + 1)), "jtp | bval | wc | rw must hold the Hessian exchange");
+  static_assert(!(C::TALIAS && C::TTAIL), "one home for the scratch");
+  static_assert(!C::TTAIL || (sizeof(PhaseA<C>) >= sizeof(PhaseB<C>) + sizeof(float) * C::NV * (C::NV + 1) && sizeof(PhaseB<C>) % 16 == 0), "the tail of the phase union must hold the Hessian exchange");
   // state + per-env model overrides
   float qpos[C::NQ], qvel[C::NV], ctrl[C::NU];
   float fric[C::NGA * 3], mass[C::NB], damp[C::NV], floss[C::NV];
@@ -403,7 +412,11 @@ struct Smem {
   //                blocks are formed); otherwise the solver's own per-row scratch jtp | bval | wc | rw, none of which is live
   //                across a factorisation (hessian_factor restores the zero words of bval that it overwrites).
   __device__ __forceinline__ float* scratch_a() { return x.a.cinert; }
-  __device__ __forceinline__ float* scratch_b() { if constexpr (C::TALIAS) return M; else return jtp; }
+  __device__ __forceinline__ float* scratch_b() {
+    if constexpr (C::TALIAS) return M;
+    else if constexpr (C::TTAIL) return reinterpret_cast<float*>(&x) + sizeof(PhaseB<C>) / sizeof(float);
+    else return jtp;
+  }
   // contacts (active only)
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
   int cpair[C::NCON];

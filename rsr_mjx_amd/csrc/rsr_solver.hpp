@@ -306,7 +306,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     // operations in order, and the rows are in registers (waited for) before the factor loop that precedes the writes
     PROF(PS_H_XCHG)
     const float dinv = rowchol_factor<C, false>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
-    if constexpr (!C::TALIAS) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }      // the null row's value (the exchange ran over it)
+    if constexpr (!C::TALIAS && !C::TTAIL) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }      // the null row's value (the exchange ran over it)
     PROF(PS_H_CHOL)
     return dinv;
   } else {
@@ -316,13 +316,22 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   WSYNC();
   PROF(PS_H_XCHG)
   const float dinv = chol_factor<C>(a, lt, s.scratch_b(), lane);
-  if constexpr (!C::TALIAS) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }
+  if constexpr (!C::TALIAS && !C::TTAIL) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }
   PROF(PS_H_CHOL)
   return dinv;
   }
 }
 
 struct SolveStats { int niter, ls_total; };
+
+// Row `lane` of the mass matrix (lanes >= NV: row 0, every use is masked).  Dims::MROW_LDS models call this at every use of
+// the row instead of keeping it in registers across the solve.
+template <class C>
+__device__ __forceinline__ void load_mrow(const Smem<C>& s, int lane, float (&Mrow)[C::NV]) {
+  const float* r = &s.M[(lane < C::NV ? lane : 0) * C::LD];
+#pragma unroll
+  for (int j = 0; j < C::NV; ++j) Mrow[j] = r[j];
+}
 
 // Whether integrate() will solve (M + dt*D) qacc = qfrc_smooth + qfrc_constraint (implicitfast, or Euler with damping
 // folded in): the only consumer of qfrc_constraint on the path.  Wave-uniform.
@@ -340,7 +349,7 @@ __device__ __forceinline__ bool implicit_integration(const Hot& m, const Smem<C>
 // Out: qacc_i, qfrc_constraint_i.
 template <class C>
 __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK],
-                      const float (&Mrow)[C::NV], float fs, float a0, float warm, bool need_force, float& qacc_out, float& qfc_out,
+                      float (&Mrow)[C::NV], float fs, float a0, float warm, bool need_force, float& qacc_out, float& qfc_out,
                       SolveStats& st, float* dbg PROF_ARG) {
   const bool dofl = lane < C::NV;
   float force[C::NCHUNK], hw[C::NCHUNK], jaref[C::NCHUNK], jv[C::NCHUNK], tmp[C::NCHUNK];
@@ -349,6 +358,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   // qacc_smooth is costed first so that the force / weight registers hold the warm-start point afterwards: the warm start
   // wins almost always, and its context (row cost, Gauss term, force, hw) is then already there instead of being
   // evaluated a third time.
+  if constexpr (C::MROW_LDS) load_mrow<C>(s, lane, Mrow);
   float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
   float jar_s[C::NCHUNK];
   jdot<C>(s, lane, nefc, nbase, rr, a0, tmp);
@@ -419,6 +429,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     search = dofl ? search : 0.0f;
     PROF(PS_HESS)
     // ---------------- line search ----------------
+    if constexpr (C::MROW_LDS) load_mrow<C>(s, lane, Mrow);
     float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
     jdot<C>(s, lane, nefc, nbase, rr, search, jv);
     float snorm = search * search, g1a = search * Ma, g1b = search * fs;
@@ -545,8 +556,7 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   kinematics<C>(m, h, s, lane PROF_PASS);
   PROF(PS_KIN)
   com_crb_mass<C>(m, h, s, lane PROF_PASS);
-#pragma unroll
-  for (int j = 0; j < C::NV; ++j) Mrow[j] = s.M[(lane < C::NV ? lane : 0) * C::LD + j];   // lanes >= NV: row 0, every use is masked
+  load_mrow<C>(s, lane, Mrow);
   PROF(PS_COMCRB)
   // velocity stage first: its scratch and the frames die before the Jacobian claims the shared LDS region
   float qvel_i = lane < C::NV ? s.qvel[lane] : 0.0f;
@@ -627,7 +637,7 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
 
 // integrate one substep after forward(): implicitfast / Euler, then _advance
 template <class C>
-__device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<C>& s, int lane, const float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
+__device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<C>& s, int lane, float (&Mrow)[C::NV], const FwdOut<C>& f PROF_ARG) {
   const Hot& m = h;
   const int lr = lrec_lane(lane);
   const int4 rj_ids = lrec<C>(h, LQ_J_IDS, lr), rj_ax = lrec<C>(h, LQ_J_AX, lr);     // joint type; (axis z, qposadr, dofadr, -)
@@ -643,6 +653,7 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
       qacc = lane < C::NV ? qacc : 0.0f;
     } else {
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;
+    if constexpr (C::MROW_LDS) load_mrow<C>(s, lane, Mrow);
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j] + (j == lane ? dd : 0.0f);
     const float dinv_i = chol_factor<C, true>(a, lt, s.scratch_a(), lane);
