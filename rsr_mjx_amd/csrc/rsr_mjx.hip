@@ -154,9 +154,18 @@ __device__ __forceinline__ float tf_uniform(uint32_t k0, uint32_t k1, int n, flo
 }
 
 struct G2Sens { float gyro[3], linvel[3], gravity[3], up[3], glin[3], gang[3], accel[3]; };
+// element i (0..2, a lane index) of a sensor triple by selects: indexing the register array with a lane index would put the
+// whole struct into scratch memory
+// (the three values pass through an empty asm: a select between loads of the struct would be rewritten into one load through
+// a selected address, which pins the struct in memory just the same)
+__device__ __forceinline__ float pick3(const float (&v)[3], int i) {
+  float a = v[0], b = v[1], c = v[2];
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+  return i == 0 ? a : (i == 1 ? b : c);
+}
 
 template <class C>
-__device__ void go2_sensors(const DModel& m, const Smem<C>& s, G2Sens& o) {
+__device__ __forceinline__ void go2_sensors(const DModel& m, const Smem<C>& s, G2Sens& o) {
   const int imu = m.env_ids[0];
   const float* R = &s.smat[9 * imu];
   V3 w = ld3(&s.sangvel[3 * imu]), v = ld3(&s.slinvel[3 * imu]);
@@ -196,7 +205,7 @@ __device__ __forceinline__ void tf_bits_batched(uint32_t k0, uint32_t k1, int n,
 // chain of register-only evaluations; the five draws (3, 3, 3, 12, 12 elements) are then one evaluation with a lane per
 // word pair and one barrier (ten evaluations with two barriers each when every split and draw went through LDS).
 template <class C>
-__device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane, float home_l) {
+__device__ __forceinline__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane, float home_l) {
 #pragma clang fp contract(off)
   const float* F = m.env_go2f;
   const bool idel = m.env_go2i[1] > 0;
@@ -228,9 +237,9 @@ __device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* ob
     if (lane < n) {
       const float u = uniform_from_bits(bits[off + lane], 0.0f, 1.0f);
       float src, scale; int dst;
-      if (d == 0) { src = idel ? s.ginfo[G2_GYRO_BUF + lane] : sn.gyro[lane]; scale = F[5]; dst = 3 + lane; }
-      else if (d == 1) { src = idel ? s.ginfo[G2_GRAV_BUF + lane] : sn.gravity[lane]; scale = F[6]; dst = 6 + lane; }
-      else if (d == 2) { src = idel ? s.ginfo[G2_LINVEL_BUF + lane] : sn.linvel[lane]; scale = F[7]; dst = lane; }
+      if (d == 0) { src = idel ? s.ginfo[G2_GYRO_BUF + lane] : pick3(sn.gyro, lane); scale = F[5]; dst = 3 + lane; }
+      else if (d == 1) { src = idel ? s.ginfo[G2_GRAV_BUF + lane] : pick3(sn.gravity, lane); scale = F[6]; dst = 6 + lane; }
+      else if (d == 2) { src = idel ? s.ginfo[G2_LINVEL_BUF + lane] : pick3(sn.linvel, lane); scale = F[7]; dst = lane; }
       else if (d == 3) { src = s.qpos[7 + lane]; scale = F[3]; dst = 9 + lane; }
       else { src = s.qvel[6 + lane]; scale = F[4]; dst = 21 + lane; }
       float a = 2.0f * u; float b = a - 1.0f; float c = b * level; float e = c * scale;
@@ -249,7 +258,7 @@ __device__ void go2_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* ob
 // cacc = accb (velocity-product part saved by smooth_forces) + sum over the body's chain of cdof * qacc, moved to the site
 // (lin + ang x dif), rotated into the site frame, plus w_local x v_local.  Wave-cooperative; every lane gets the result.
 template <class C>
-__device__ void go2_accelerometer(const DModel& m, const Smem<C>& s, int lane, float qacc_i, G2Sens& o) {
+__device__ __forceinline__ void go2_accelerometer(const DModel& m, const Smem<C>& s, int lane, float qacc_i, G2Sens& o) {
   const int imu = m.env_ids[0], b = m.site_bodyid[imu];
   const bool on = lane < C::NV && ((m.body_dofmask[b] >> lane) & 1);
   float c6[6];
@@ -269,14 +278,14 @@ __device__ void go2_accelerometer(const DModel& m, const Smem<C>& s, int lane, f
 
 // joystick.py:341-366: element t of obs["privileged_state"]; read right after go2_obs (info: old last_contact, air + dt)
 template <class C>
-__device__ float go2_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& sn, const float* obs_lds, int t) {
+__device__ __forceinline__ float go2_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& sn, const float* obs_lds, int t) {
   if (t < 48) return obs_lds[t];
   t -= 48;
-  if (t < 3) return sn.gyro[t];
-  if (t < 6) return sn.accel[t - 3];
-  if (t < 9) return sn.gravity[t - 6];
-  if (t < 12) return sn.linvel[t - 9];
-  if (t < 15) return sn.gang[t - 12];
+  if (t < 3) return pick3(sn.gyro, t);
+  if (t < 6) return pick3(sn.accel, t - 3);
+  if (t < 9) return pick3(sn.gravity, t - 6);
+  if (t < 12) return pick3(sn.linvel, t - 9);
+  if (t < 15) return pick3(sn.gang, t - 12);
   if (t < 27) return s.qpos[7 + t - 15] - m.env_go2_home[7 + t - 15];
   if (t < 39) return s.qvel[6 + t - 27];
   if (t < 51) return s.aforce[t - 39];
@@ -312,12 +321,9 @@ __device__ __forceinline__ float go2_priv_gather(const DModel& m, const Smem<C>&
   float v = *p;
   if (k >= 15 && k < 27) v = v - h;
   if constexpr (FIRST) {
-    float sv = sn.gyro[0];
-    sv = k == 1 ? sn.gyro[1] : sv; sv = k == 2 ? sn.gyro[2] : sv;
-    sv = k == 3 ? sn.accel[0] : sv; sv = k == 4 ? sn.accel[1] : sv; sv = k == 5 ? sn.accel[2] : sv;
-    sv = k == 6 ? sn.gravity[0] : sv; sv = k == 7 ? sn.gravity[1] : sv; sv = k == 8 ? sn.gravity[2] : sv;
-    sv = k == 9 ? sn.linvel[0] : sv; sv = k == 10 ? sn.linvel[1] : sv; sv = k == 11 ? sn.linvel[2] : sv;
-    sv = k == 12 ? sn.gang[0] : sv; sv = k == 13 ? sn.gang[1] : sv; sv = k == 14 ? sn.gang[2] : sv;
+    const int grp = k < 0 ? 0 : k / 3, comp = k < 0 ? 0 : k - 3 * grp;
+    const float v_gy = pick3(sn.gyro, comp), v_ac = pick3(sn.accel, comp), v_gr = pick3(sn.gravity, comp), v_li = pick3(sn.linvel, comp), v_ga = pick3(sn.gang, comp);
+    const float sv = grp == 0 ? v_gy : (grp == 1 ? v_ac : (grp == 2 ? v_gr : (grp == 3 ? v_li : v_ga)));
     if (k >= 0 && k < 15) v = sv;
   }
   if (k == 74) v = kick_flag;
@@ -911,7 +917,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     if (lane < 3 * nb) v = s.ginfo[base + 3 + off];
     WSYNC();
     if (lane < 3 * nb) s.ginfo[base + off] = v;
-    if (lane < 3) { s.ginfo[G2_GYRO_BUF + nb + lane] = sn.gyro[lane]; s.ginfo[G2_LINVEL_BUF + nb + lane] = sn.linvel[lane]; s.ginfo[G2_GRAV_BUF + nb + lane] = sn.gravity[lane]; }
+    if (lane < 3) { s.ginfo[G2_GYRO_BUF + nb + lane] = pick3(sn.gyro, lane); s.ginfo[G2_LINVEL_BUF + nb + lane] = pick3(sn.linvel, lane); s.ginfo[G2_GRAV_BUF + nb + lane] = pick3(sn.gravity, lane); }
     WSYNC();
   }
   PROF(PS_E_FIFO)
@@ -1080,7 +1086,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
   if (lane < 4) {
 #pragma clang fp contract(off)
-    float c = (float)contact[lane], nc = 1.0f - c;
+    float c = (float)(lane == 0 ? contact[0] : (lane == 1 ? contact[1] : (lane == 2 ? contact[2] : contact[3]))), nc = 1.0f - c;   // (no lane-indexed array: scratch)
     s.ginfo[G2_AIR + lane] = (s.ginfo[G2_AIR + lane] + dt) * nc;
     s.ginfo[G2_CONTACT_T + lane] = (s.ginfo[G2_CONTACT_T + lane] + dt) * c;
     s.ginfo[G2_LAST_CONTACT + lane] = c;
