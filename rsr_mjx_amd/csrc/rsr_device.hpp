@@ -28,40 +28,49 @@ enum { INT_EULER = 0, INT_IMPLICITFAST = 3 };
 enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
 
 // ---- device view of the model blob (pointers into one device copy of the blob) ----
+// Pointers of the model view are global-memory pointers, typed as such in device code: a pointer loaded from a struct in memory
+// has no known address space, so the compiler would issue FLAT loads through it -- which count on the LDS counter as well, so
+// that every wait for an LDS read also waits for the model loads in flight (and cost 64-bit address arithmetic per lane).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RSR_GP(T) const T __attribute__((address_space(1)))*
+#else
+#define RSR_GP(T) const T*
+#endif
+using gp_i = RSR_GP(int); using gp_f = RSR_GP(float); using gp_u = RSR_GP(unsigned); using gp_q = RSR_GP(int4);
 struct DModel {
-  const int *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr, *body_depth;
-  const float *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
-  const int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited, *jnt_actfrclimited;
-  const float *jnt_pos, *jnt_axis, *jnt_range, *jnt_actfrcrange, *jnt_solref, *jnt_solimp, *jnt_margin;
-  const int *dof_bodyid, *dof_jntid;
-  const unsigned *dof_ancmask, *dof_velmask, *body_dofmask, *body_submask;
-  const float *dof_armature, *dof_damping, *dof_frictionloss, *dof_invweight0, *dof_solref, *dof_solimp;
-  const int *geom_bodyid, *geom_priority;
-  const float *geom_size, *geom_pos, *geom_quat, *geom_friction;
-  const int* geom_slot_ids;      // geom id of every geom slot (the geoms that appear in a contact pair, in geom order)
-  const int *site_bodyid;
-  const float *site_pos, *site_quat;
-  const int *eq_obj1id, *eq_obj2id, *eq_active0;
-  const float *eq_data, *eq_solref, *eq_solimp;
-  const int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
-  const float *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
-  const int *pair_geom1, *pair_geom2, *pair_kind, *pair_condim;
-  const float *pair_solref, *pair_solimp, *pair_margin, *pair_gap;
-  const int *fric_dofs, *limit_jnts;
+  gp_i body_parentid, body_rootid, body_jntnum, body_jntadr, body_dofnum, body_dofadr, body_depth;
+  gp_f body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0;
+  gp_i jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited, jnt_actfrclimited;
+  gp_f jnt_pos, jnt_axis, jnt_range, jnt_actfrcrange, jnt_solref, jnt_solimp, jnt_margin;
+  gp_i dof_bodyid, dof_jntid;
+  gp_u dof_ancmask, dof_velmask, body_dofmask, body_submask;
+  gp_f dof_armature, dof_damping, dof_frictionloss, dof_invweight0, dof_solref, dof_solimp;
+  gp_i geom_bodyid, geom_priority;
+  gp_f geom_size, geom_pos, geom_quat, geom_friction;
+  gp_i geom_slot_ids;      // geom id of every geom slot (the geoms that appear in a contact pair, in geom order)
+  gp_i site_bodyid;
+  gp_f site_pos, site_quat;
+  gp_i eq_obj1id, eq_obj2id, eq_active0;
+  gp_f eq_data, eq_solref, eq_solimp;
+  gp_i actuator_trnid, actuator_ctrllimited, actuator_forcelimited;
+  gp_f actuator_gear, actuator_gainprm, actuator_biasprm, actuator_ctrlrange, actuator_forcerange;
+  gp_i pair_geom1, pair_geom2, pair_kind, pair_condim;
+  gp_f pair_solref, pair_solimp, pair_margin, pair_gap;
+  gp_i fric_dofs, limit_jnts;
   // flattened one-level tables (rsr_mjx_amd/model.py: flattened_tables)
-  const int *pair_b1, *pair_b2, *pair_root1, *pair_root2, *dof_rootid, *dof_jtype, *dof_k, *dof_act, *dof_afl, *body_jtype, *body_qposadr;
-  const unsigned *pair_mask1, *pair_mask2;
-  const float *pair_tw, *pair_incl, *dof_afrange, *body_jpos, *body_jaxis;
+  gp_i pair_b1, pair_b2, pair_root1, pair_root2, dof_rootid, dof_jtype, dof_k, dof_act, dof_afl, body_jtype, body_qposadr;
+  gp_u pair_mask1, pair_mask2;
+  gp_f pair_tw, pair_incl, dof_afrange, body_jpos, body_jaxis;
   // per-lane constant records [LQ_COUNT][64] of 16-byte quads (rsr_mjx_amd/model.py: lane_records)
-  const int4* lane_rec;
+  gp_q lane_rec;
   // height field (at most one): size = (x, y, z, base) half extents / elevation scale, data [nrow*ncol] in [0, 1]
-  const float *hfield_size, *hfield_data;
-  const int *hfield_nrow, *hfield_ncol;
-  const float *qpos0;
-  const int *env_ids;
-  const float *env_action_scale, *env_ctrl_lo, *env_ctrl_hi, *env_reset, *env_reward;
-  const float *env_go2f, *env_go2_scales, *env_go2_home, *env_go2_soft;
-  const int *env_go2i;
+  gp_f hfield_size, hfield_data;
+  gp_i hfield_nrow, hfield_ncol;
+  gp_f qpos0;
+  gp_i env_ids;
+  gp_f env_action_scale, env_ctrl_lo, env_ctrl_hi, env_reset, env_reward;
+  gp_f env_go2f, env_go2_scales, env_go2_home, env_go2_soft;
+  gp_i env_go2i;
   float timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, integrator, disable_eulerdamp, disable_refsafe;
   int nfric, nlimit, maxdepth;
@@ -74,7 +83,7 @@ struct DModel {
 // wait, and every stage's record fetch first loads m.lane_rec; a wave reads these few dozen times per substep.  Held in
 // SGPRs (or spilled to VGPR lanes, still ~10x cheaper than the load).
 struct Hot {
-  const int4* lane_rec;
+  gp_q lane_rec;
   float timestep, grav0, grav1, grav2, impratio, tolerance, ls_tolerance, meaninertia;
   int maxdepth, max_sub, max_chain, integrator, disable_eulerdamp, disable_refsafe, iterations, ls_iterations, n_frames;
 };

@@ -1375,7 +1375,7 @@ extern "C" int rsr_model_dims(const rsr_model* m, rsr_dims* out) {
 extern "C" void rsr_model_destroy(rsr_model* m) { delete m; }
 
 static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
-#define P(T, name) { ptrdiff_t o = m->offset_of(#name); if (o < 0) return fail(RSR_ERR_ARG, "blob lacks field " #name); dm.name = reinterpret_cast<const T*>(dbase + o); }
+#define P(T, name) { ptrdiff_t o = m->offset_of(#name); if (o < 0) return fail(RSR_ERR_ARG, "blob lacks field " #name); dm.name = (decltype(dm.name))(dbase + o); }
   P(int, body_parentid) P(int, body_rootid) P(int, body_jntnum) P(int, body_jntadr) P(int, body_dofnum) P(int, body_dofadr) P(int, body_depth)
   P(float, body_pos) P(float, body_quat) P(float, body_ipos) P(float, body_iquat) P(float, body_mass) P(float, body_inertia) P(float, body_invweight0)
   P(int, jnt_type) P(int, jnt_qposadr) P(int, jnt_dofadr) P(int, jnt_bodyid) P(int, jnt_limited) P(int, jnt_actfrclimited)
