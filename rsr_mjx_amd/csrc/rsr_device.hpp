@@ -288,7 +288,13 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-#define WSYNC() __syncthreads()
+// One wave is one workgroup, so a "barrier" only has to order this wave's own LDS accesses.  The LDS executes a wave's
+// instructions in order -- a read issued after a write of the same wave observes it -- so a wavefront-scope fence is enough: it
+// stops the compiler from moving memory operations across it and emits no instruction.  (__syncthreads() in a one-wave
+// workgroup drops the s_barrier but keeps the workgroup-scope fence: s_waitcnt lgkmcnt(0) after every write phase, one LDS
+// round trip of idle time per barrier, a few dozen per substep.)  Nothing in the kernels passes data between lanes through
+// global memory across a WSYNC: the hand-off between work units has its own waits.
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
 // Visits the set bits of `mask` four candidates per trip: f(i, on) with on = false (and i = 0) once the mask is
 // exhausted.  The four LDS loads of a trip do not depend on each other, so they are in flight together and a walk over
