@@ -1591,7 +1591,8 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   const int lr = lrec_lane(lane);
   const int4 rl0 = lrec<C>(h, LQ_L_0, lr), rl1 = lrec<C>(h, LQ_L_1, lr);
   const int4 re0 = lrec<C>(h, LQ_E_0, lr), re1 = lrec<C>(h, LQ_E_1, lr), re2 = lrec<C>(h, LQ_E_2, lr), re3 = lrec<C>(h, LQ_E_3, lr), re4 = lrec<C>(h, LQ_E_4, lr);
-  const int4 rf0 = lrec<C>(h, LQ_F_0, lr), rf1 = lrec<C>(h, LQ_F_1, lr), rf2 = lrec<C>(h, LQ_F_2, lr);
+  const int4 rf0 = lrec<C>(h, LQ_F_0, lr);
+  const gp_f qpos0_tab = m.qpos0;
   // active joint limits, compacted in slot order (slot = index into limit_jnts; its constants are record LQ_L_*[slot])
   int lim_active = 0;
   if (lane < C::NL) {
@@ -1606,15 +1607,49 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   const int ncon = s.ncon;
   const int nefc = r_con + C::NPYR * ncon;
   WSYNC();
+  // ---- every record this stage reads through a data-dependent index (pair of a contact, slot of an active limit), fetched
+  // here in ONE batch: left where they are used -- inside the loops and the per-row branches below -- each fetch was a global
+  // round trip of its own behind an LDS read, five to seven in a row per substep.
+  //  * lane c < ncon: the pair record of contact c (bodies / dof masks, geom slots, friction rule) -> per-contact table in LDS
+  //    (s.wc, free until the Hessian), read by the base-row and friction loops;
+  //  * lane < nl: limit record of its compacted slot;
+  //  * per constraint row of this lane: the four quads its regulariser needs (A..D, by row type).
+  int4 ct3, ct0, ct2, lq0;
+  {
+    const int p = s.cpair[lane < ncon ? lane : 0];
+    const int pi = lane < ncon ? p : 0;
+    ct3 = h.lane_rec[LQ_P_3 * 64 + pi]; ct0 = h.lane_rec[LQ_P_0 * 64 + pi]; ct2 = h.lane_rec[LQ_P_2 * 64 + pi];
+    const int sl = lane < nl ? s.lim_jnt[lane] : 0;
+    lq0 = h.lane_rec[LQ_L_0 * 64 + sl];
+  }
+  int4 qa[C::NCHUNK], qb[C::NCHUNK], qc[C::NCHUNK], qd[C::NCHUNK];
+#pragma unroll
+  for (int ch = 0; ch < C::NCHUNK; ++ch) {
+    const int r = lane + 64 * ch;
+    int base = LQ_F_0, idx = 0, third = 2, fourth = 2;            // (rows without a record: any valid address)
+    if (r >= r_fric && r < r_lim) { idx = r - r_fric; }
+    else if (r >= r_lim && r < r_con) { base = LQ_L_0; idx = s.lim_jnt[r - r_lim]; fourth = 3; }
+    else if (r >= r_con && r < nefc) { base = LQ_P_0; idx = s.cpair[(r - r_con) / C::NPYR]; third = 4; fourth = 5; }
+    const gp_q tab = h.lane_rec + base * 64 + idx;
+    qa[ch] = tab[0]; qb[ch] = tab[64]; qc[ch] = tab[third * 64]; qd[ch] = tab[fourth * 64];
+  }
+  float q0_e1 = 0.0f, q0_e0 = 0.0f;
+  if constexpr (C::DREX) { if (lane < C::NEQ) { q0_e1 = s.dx_qpos0[re1.y]; q0_e0 = s.dx_qpos0[re0.y]; } }
+  else { const int e1 = lane < C::NEQ ? re1.y : 0, e0 = lane < C::NEQ ? re0.y : 0; q0_e1 = qpos0_tab[e1]; q0_e0 = qpos0_tab[e0]; }
   // zero the sparse rows, then poke their entries
   for (int t = lane; t < r_con * LD; t += 64) s.x.b.J[t] = 0.0f;
   if (lane < LD) s.x.b.J[C::NBASE * LD + lane] = 0.0f;      // null row (phase A used this memory)
   if (lane < 4) { s.bval[C::NBASE + lane] = 0.0f; s.bmu[C::NBASE + lane] = 0.0f; }
   for (int t = lane; t < r_con; t += 64) s.bmu[t] = 0.0f;
+  int* const ctab = reinterpret_cast<int*>(s.wc);          // [ncon][8]: dof masks 1, 2; bodies 1, 2; geom slots 1, 2; friction rule
+  if (lane < ncon) {
+    int* t = &ctab[8 * lane];
+    t[0] = ct3.x; t[1] = ct3.y; t[2] = ct3.z; t[3] = ct3.w; t[4] = ct0.x; t[5] = ct0.y; t[6] = ct2.w;
+  }
   WSYNC();
   // equality e = lane (joint coupling): dif = qpos[j2] - qpos0[j2], polynomial data[0..4]
   float eq_dif = 0.0f;
-  if (lane < C::NEQ && re1.x) eq_dif = s.qpos[re1.y] - mdl_qpos0<C>(m, s, re1.y);
+  if (lane < C::NEQ && re1.x) eq_dif = s.qpos[re1.y] - q0_e1;
   if (lane < C::NEQ && re0.x) {
     const int e = lane;
     float deriv = asf(re2.y) + eq_dif * (2.0f * asf(re2.z) + eq_dif * (3.0f * asf(re2.w) + eq_dif * 4.0f * asf(re3.x)));
@@ -1623,8 +1658,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   }
   if (lane < C::NF) { s.x.b.J[(r_fric + lane) * LD + rf0.x] = 1.0f; s.sdof[r_fric + lane] = rf0.x; }
   if (lane < nl) {
-    const int sl = s.lim_jnt[lane];
-    const int4 q0 = lrec<C>(h, LQ_L_0, sl);
+    const int4 q0 = lq0;
     float q = s.qpos[q0.x];
     float dmin = q - asf(q0.z), dmax = asf(q0.w) - q;
     s.x.b.J[(r_lim + lane) * LD + q0.y] = dmin < dmax ? 1.0f : -1.0f;
@@ -1634,13 +1668,14 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   // contact base rows: item (contact c, dof i) fills normal / tangent 1 / tangent 2 / torsion
   for (int t = lane; t < ncon * C::NV; t += 64) {
     int c = t / C::NV, i = t - c * C::NV;
-    int p = s.cpair[c];
-    const int4 rp3 = lrec<C>(h, LQ_P_3, p);
+    const int* ct = &ctab[8 * c];
+    const unsigned mask1 = (unsigned)ct[0], mask2 = (unsigned)ct[1];
+    const int body1 = ct[2], body2 = ct[3];
     V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
     make_frame(n, nn, t1, t2);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
-    float in1 = (((unsigned)rp3.x >> i) & 1) ? 1.0f : 0.0f, in2 = (((unsigned)rp3.y >> i) & 1) ? 1.0f : 0.0f;
-    V3 o1 = pos - ld3(&s.com[3 * rp3.z]), o2 = pos - ld3(&s.com[3 * rp3.w]);
+    float in1 = ((mask1 >> i) & 1) ? 1.0f : 0.0f, in2 = ((mask2 >> i) & 1) ? 1.0f : 0.0f;
+    V3 o1 = pos - ld3(&s.com[3 * body1]), o2 = pos - ld3(&s.com[3 * body2]);
     V3 jp = (lin + cross(ang, o2)) * in2 - (lin + cross(ang, o1)) * in1;
     V3 jr = ang * (in2 - in1);
     float* Jr = &s.x.b.J[(r_con + C::NBC * c) * LD + i];
@@ -1651,9 +1686,8 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   // friction coefficient of each contact base row (normal: unused)
   for (int t = lane; t < ncon * C::NBC; t += 64) {
     int c = t / C::NBC, k = t - c * C::NBC;
-    int p = s.cpair[c];
-    const int4 rp0 = lrec<C>(h, LQ_P_0, p), rp2 = lrec<C>(h, LQ_P_2, p);
-    const int g1 = rp0.x, g2 = rp0.y, rule = rp2.w;       // rule: 0 = max of the two geoms, 1 / 2 = the higher-priority geom's
+    const int* ct = &ctab[8 * c];
+    const int g1 = ct[4], g2 = ct[5], rule = ct[6];       // rule: 0 = max of the two geoms, 1 / 2 = the higher-priority geom's
     float a0 = s.fric[3 * g1], a1 = s.fric[3 * g1 + 1], b0 = s.fric[3 * g2], b1 = s.fric[3 * g2 + 1];
     float f0 = rule == 0 ? fmaxf(a0, b0) : (rule == 1 ? a0 : b0), f1 = rule == 0 ? fmaxf(a1, b1) : (rule == 1 ? a1 : b1);
     s.bmu[r_con + t] = k == 0 ? 0.0f : (k == 3 ? f1 : f0);
@@ -1668,36 +1702,32 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
     if (r < nefc) {
       float pos = 0, invw = 0, sr0, sr1, fl = -1.0f; Solimp si;
       o.bn = r; o.bk = r;
+      const int4 q0 = qa[ch], q1 = qb[ch], q2 = qc[ch], q3 = qd[ch];      // the row's record (fetched above), by row type:
       if (r < r_fric) {                      // equality row r = lane (first chunk)
         float poly = asf(re2.x) + eq_dif * (asf(re2.y) + eq_dif * (asf(re2.z) + eq_dif * (asf(re2.w) + eq_dif * asf(re3.x))));
-        pos = s.qpos[re0.y] - mdl_qpos0<C>(m, s, re0.y) - poly;
+        pos = s.qpos[re0.y] - q0_e0 - poly;
         invw = asf(re0.w);
         sr0 = asf(re3.y); sr1 = asf(re3.z);
         si.v[0] = asf(re3.w); si.v[1] = asf(re4.x); si.v[2] = asf(re4.y); si.v[3] = asf(re4.z); si.v[4] = asf(re4.w);
-      } else if (r < r_lim) {                // friction row: slot r - r_fric
-        const int sl = r - r_fric;
-        const int4 q0 = lrec<C>(h, LQ_F_0, sl), q1 = lrec<C>(h, LQ_F_1, sl), q2 = lrec<C>(h, LQ_F_2, sl);
+      } else if (r < r_lim) {                // friction row: F_0, F_1, F_2 of slot r - r_fric
         invw = asf(q0.y); sr0 = asf(q0.z); sr1 = asf(q0.w);
         si.v[0] = asf(q1.x); si.v[1] = asf(q1.y); si.v[2] = asf(q1.z); si.v[3] = asf(q1.w); si.v[4] = asf(q2.x);
         fl = s.floss[q0.x];
-      } else if (r < r_con) {                // active limit: slot from the compaction
-        const int sl = s.lim_jnt[r - r_lim];
-        const int4 q0 = lrec<C>(h, LQ_L_0, sl), q1 = lrec<C>(h, LQ_L_1, sl), q2 = lrec<C>(h, LQ_L_2, sl), q3 = lrec<C>(h, LQ_L_3, sl);
+      } else if (r < r_con) {                // active limit: L_0 .. L_3 of the slot from the compaction
         float q = s.qpos[q0.x];
         pos = fminf(q - asf(q0.z), asf(q0.w) - q) - asf(q1.x);
         invw = asf(q1.y); sr0 = asf(q1.z); sr1 = asf(q1.w);
         si.v[0] = asf(q2.x); si.v[1] = asf(q2.y); si.v[2] = asf(q2.z); si.v[3] = asf(q2.w); si.v[4] = asf(q3.x);
-      } else {
-        int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c, p = s.cpair[c];
-        const int4 q0 = lrec<C>(h, LQ_P_0, p), q1 = lrec<C>(h, LQ_P_1, p), q4 = lrec<C>(h, LQ_P_4, p), q5 = lrec<C>(h, LQ_P_5, p);
+      } else {                               // pyramid row of contact c: P_0, P_1, P_4, P_5 of its pair
+        int c = (r - r_con) / C::NPYR, e = (r - r_con) - C::NPYR * c;
         pos = s.cdist[c] - asf(q0.w);
         o.bn = r_con + C::NBC * c; o.bk = o.bn + 1 + (e >> 1);
         float f0 = s.bmu[o.bn + 1];
         o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
         float tw = asf(q1.w);
         invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / h.impratio;
-        sr0 = asf(q4.x); sr1 = asf(q4.y);
-        si.v[0] = asf(q4.z); si.v[1] = asf(q4.w); si.v[2] = asf(q5.x); si.v[3] = asf(q5.y); si.v[4] = asf(q5.z);
+        sr0 = asf(q2.x); sr1 = asf(q2.y);
+        si.v[0] = asf(q2.z); si.v[1] = asf(q2.w); si.v[2] = asf(q3.x); si.v[3] = asf(q3.y); si.v[4] = asf(q3.z);
       }
       float k, b, imp;
       kbi(h, sr0, sr1, si, pos, k, b, imp);
