@@ -143,7 +143,7 @@ struct StepArgs {
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
           int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false,
-          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false>
+          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false, bool ARROW_ = false>
 struct Dims {
   // LDS diet of the single-iteration models (Go2: one Hessian per substep, explicit Euler): the transpose / exchange scratch T
   // has no storage of its own -- before the solve it is the dead part of phase A (cinert .. cfrcsum), from the Hessian on it
@@ -173,7 +173,17 @@ struct Dims {
   static constexpr int NISO = ISO1_ - ISO0_;
   static constexpr int NA = NV_ - NISO;
   static constexpr bool ROWCHOL = NA <= 16 && NISO <= 16 && NA >= NISO;
-  static constexpr int NCH = ROWCHOL ? NA : NV_;
+  // Block-arrow factorisation (Go2): a floating trunk (dofs 0 .. ANT) carrying ALEGS legs of ALEGN dofs each; legs couple to the
+  // trunk and never to each other -- not in the mass matrix (separate branches of one tree) and not in J^T D J (every
+  // constraint row touches the trunk and at most one leg; checked on the host).  Eliminating the legs first leaves no fill
+  // between legs, so the four leg blocks are eliminated TOGETHER, one per 16-lane DPP row, each row working on its 9 x 9
+  // [leg | trunk] matrix; the four Schur complements are summed onto the trunk, which every row then factors for itself.
+  // 36 dependent steps of one DPP fmac per column instead of 153 v_readlane + fma pairs, and 9 + 9 factor registers per lane
+  // instead of 18 + 18.  NCH = columns a lane keeps.
+  static constexpr bool ARROW = ARROW_;
+  static constexpr int ANT = 6, ALEGN = 3, ALEGS = ARROW_ ? (NV_ - 6) / 3 : 0;
+  static_assert(!ARROW_ || (NV_ == 6 + 3 * ((NV_ - 6) / 3) && (NV_ - 6) / 3 == 4 && !ROWCHOL), "block-arrow layout: 6 trunk dofs + 4 legs of 3");
+  static constexpr int NCH = ROWCHOL ? NA : (ARROW_ ? 9 : NV_);
   static constexpr int dof_of_col_a(int c) { return c < ISO0_ ? c : c + NISO; }      // block A column -> dof
   static constexpr int dof_of_col_b(int c) { return ISO0_ + c; }                     // block B column -> dof
   static constexpr bool coupled(int i, int j) { return (i >= ISO0_ && i < ISO1_) == (j >= ISO0_ && j < ISO1_); }
@@ -955,6 +965,111 @@ __device__ __forceinline__ float rowchol_solve(const float (&a)[C::NCH], const f
   x *= dinv;
   static_for<0, C::NCH>([&](auto kc) { constexpr int k = C::NCH - 1 - decltype(kc)::value; fmac_self_bcast<k>(x, lt[k]); });   // backward
   return __shfl(x, lane < C::NV ? rowchol_lane<C>(lane) : 0);
+}
+
+// =====================================================================================
+// Block-arrow L D L^T (Dims::ARROW).  Lane (row = lane >> 4, pos = lane & 15): pos 0..2 = the dofs of leg `row`, pos 3..8 = the
+// trunk dofs (a copy per row), pos >= 9 idle.  a[c]: column c of the row's local 9 x 9 matrix (c < 3: the leg, c >= 3: trunk).
+// Elimination order legs, then trunk: a different order of the same exact arithmetic than the natural-order factorisation
+// (results differ from it in rounding only).
+// =====================================================================================
+template <class C> __device__ __forceinline__ int arrow_dof(int lane) {           // dof of a lane, -1 for idle lanes
+  const int row = lane >> 4, pos = lane & 15;
+  return pos < C::ALEGN ? C::ANT + C::ALEGN * row + pos : (pos < C::ANT + C::ALEGN ? pos - C::ALEGN : -1);
+}
+template <class C> __device__ __forceinline__ int arrow_lane(int dof) {           // lane of a dof (the trunk: its copy in row 0)
+  return dof < C::ANT ? C::ALEGN + dof : 16 * ((dof - C::ANT) / C::ALEGN) + (dof - C::ANT) % C::ALEGN;
+}
+template <int K, int N, class A>
+__device__ __forceinline__ float arrow_step(A& a, int pos) {                      // one elimination step of the local matrices
+  float piv = row_bcast<K>(a[K]);
+  piv = piv > 0.0f ? piv : RSR_MINVAL;
+  float rcp = __builtin_amdgcn_rcpf(piv);
+  rcp = rcp + rcp * (1.0f - piv * rcp);
+  const float u = a[K];
+  a[K] = (pos > K) ? u * rcp : 0.0f;
+  const float lik = a[K];
+  static_for<K + 1, N>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j == K + 1) fmac_row_bcast<j, true>(a[j], u, lik); else fmac_row_bcast<j, false>(a[j], u, lik);
+  });
+  return rcp;
+}
+// src: natural-order [NV][LD] matrix in LDS; diag: added to this lane's diagonal entry (value for the lane's dof; the trunk's is
+// taken from row 0 only).  lt[] = row of the transposed local factor, through the LDS scratch T (>= 4 * 81 floats).
+template <class C, bool HAS_DIAG = false>
+__device__ __forceinline__ float arrow_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
+  static_assert(C::ARROW && C::NCH == 9, "block-arrow factorisation");
+  constexpr int N = 9, NL = C::ALEGN;
+  const int row = lane >> 4, pos = lane & 15, dofl = arrow_dof<C>(lane);
+  const bool trunk_copy = pos >= NL && row > 0;          // trunk lanes of rows 1..3: their trunk block starts at zero
+#pragma unroll
+  for (int c = 0; c < N; ++c) a[c] = 0.0f;
+  if (dofl >= 0) {
+    const float* r = src + dofl * C::LD;
+    // the leg columns: a leg lane's own row; a trunk lane's entries H[trunk][leg] are read as H[leg][trunk] -- in natural order
+    // they sit above the diagonal, and the Hessian exchange only writes the lower triangle
+    const float* lc = pos < NL ? r + C::ANT + NL * row : src + (C::ANT + NL * row) * C::LD + (pos - NL);
+    const int lstride = pos < NL ? 1 : C::LD;
+#pragma unroll
+    for (int c = 0; c < NL; ++c) a[c] = lc[c * lstride];
+    float t[C::ANT];
+#pragma unroll
+    for (int c = 0; c < C::ANT; ++c) t[c] = r[c];
+#pragma unroll
+    for (int c = 0; c < C::ANT; ++c) a[NL + c] = trunk_copy ? 0.0f : t[c];
+  }
+  if constexpr (HAS_DIAG) {
+    const float dg = trunk_copy ? 0.0f : diag;
+#pragma unroll
+    for (int c = 0; c < N; ++c) if (c == pos) a[c] += dg;
+  }
+  float dinv = 0.0f;
+  static_for<0, NL>([&](auto kc) {                        // the four legs, together
+    constexpr int k = decltype(kc)::value;
+    const float rcp = arrow_step<k, N>(a, pos);
+    if (pos == k) dinv = rcp;
+  });
+  // the legs' Schur complements meet on the trunk: every row ends with the same sum (same bits: the adds commute)
+#pragma unroll
+  for (int c = NL; c < N; ++c) { float v = a[c]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); a[c] = v; }
+  static_for<NL, N>([&](auto kc) {                        // the trunk, once per row (identical copies)
+    constexpr int k = decltype(kc)::value;
+    const float rcp = arrow_step<k, N>(a, pos);
+    if (pos == k) dinv = rcp;
+  });
+  // transpose through LDS, per row: T[row][c][pos] = a[c]; lt[k] = L[k][pos] = a[pos] of lane (row, k)
+  if (pos < N) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) T[(row * N + c) * N + pos] = a[c];
+  }
+  WSYNC();
+#pragma unroll
+  for (int k = 0; k < N; ++k) lt[k] = 0.0f;
+  if (pos < N) {
+    const float* col = &T[(row * N + pos) * N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) lt[k] = col[k];
+  }
+  WSYNC();
+  return dinv;
+}
+// Solves with the block-arrow factor.  b / result: natural order (lane i = dof i).
+template <class C>
+__device__ __forceinline__ float arrow_solve(const float (&a)[C::NCH], const float (&lt)[C::NCH], float dinv, float b, int lane) {
+  constexpr int N = 9, NL = C::ALEGN;
+  const int row = lane >> 4, pos = lane & 15, dofl = arrow_dof<C>(lane);
+  float x = __shfl(b, dofl >= 0 ? dofl : 0);
+  x = (dofl >= 0 && !(pos >= NL && row > 0)) ? x : 0.0f;              // the trunk's right-hand side enters once (row 0)
+  static_for<0, NL>([&](auto kc) { constexpr int k = decltype(kc)::value; fmac_self_bcast<k>(x, a[k]); });        // legs, forward
+  {
+    float v = x; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);      // trunk: b - sum over the legs of L y
+    x = pos >= NL ? v : x;
+  }
+  static_for<NL, N>([&](auto kc) { constexpr int k = decltype(kc)::value; fmac_self_bcast<k>(x, a[k]); });        // trunk, forward
+  x *= dinv;
+  static_for<0, N>([&](auto kc) { constexpr int k = N - 1 - decltype(kc)::value; fmac_self_bcast<k>(x, lt[k]); });  // backward
+  return __shfl(x, lane < C::NV ? arrow_lane<C>(lane) : 0);
 }
 
 // broadcast a per-dof vector (lane i holds v_i) and multiply by a register-resident matrix row

@@ -23,7 +23,7 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_N
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
-                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true>;
+                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true, /*ARROW*/ true>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
@@ -1302,10 +1302,18 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
     }
     if (!okg) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: geom_slot_ids do not match the kernel's geom slots (Dims::NGA) or miss a pair geom"); }
   }
-  if (d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::TALIAS) {   // the Go2 kernels reuse the mass matrix's storage after the one Hessian of a substep
-    const int* it = static_cast<const int*>(m->find("opt_iterations"));
-    const int* ig = static_cast<const int*>(m->find("opt_integrator"));
-    if (it[0] != 1 || ig[0] != rsr::INT_EULER) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the Go2 kernels are built for opt.iterations = 1 and the Euler integrator"); }
+  if (d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::ARROW) {
+    // the Go2 kernels factor M and H in block-arrow form (Dims::ARROW): dofs 0..5 are the trunk, every further group of three dofs
+    // is a leg, and no body chain and no contact pair may touch two legs
+    using G = rsr::Go2Dims;
+    auto legs_of = [](unsigned mask) { int n = 0; for (int l = 0; l < G::ALEGS; ++l) n += ((mask >> (G::ANT + G::ALEGN * l)) & 7u) != 0u; return n; };
+    int nbm = 0, npm = 0;
+    const unsigned* bm = static_cast<const unsigned*>(m->find("body_dofmask", &nbm));
+    const unsigned* pm1 = static_cast<const unsigned*>(m->find("pair_mask1", &npm)); const unsigned* pm2 = static_cast<const unsigned*>(m->find("pair_mask2"));
+    bool oka = d.nv == G::NV && bm && pm1 && pm2;
+    for (int b = 0; oka && b < nbm; ++b) oka = legs_of(bm[b]) <= 1;
+    for (int q = 0; oka && q < npm; ++q) oka = legs_of(pm1[q] | pm2[q]) <= 1;
+    if (!oka) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the Go2 kernels need a trunk of 6 dofs carrying legs of 3 dofs that only couple through the trunk"); }
   }
   int npc = 0; const int* pc = static_cast<const int*>(m->find("pair_condim", &npc));
   for (int i = 0; i < npc; ++i) if (pc[i] != want_condim) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: contact pairs must all have the condim the kernel is built for (Airbot 4, Go2 3)"); }

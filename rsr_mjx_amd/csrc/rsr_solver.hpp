@@ -309,6 +309,11 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     if constexpr (!C::TALIAS && !C::TTAIL) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }      // the null row's value (the exchange ran over it)
     PROF(PS_H_CHOL)
     return dinv;
+  } else if constexpr (C::ARROW) {
+    PROF(PS_H_XCHG)
+    const float dinv = arrow_factor<C>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
+    PROF(PS_H_CHOL)
+    return dinv;
   } else {
   const float* Trow = &s.scratch_b()[(lane < C::NV ? lane : 0) * C::LD];
 #pragma unroll
@@ -425,6 +430,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     }
     float search;
     if constexpr (C::ROWCHOL) search = -rowchol_solve<C>(a, lt, dinv, grad, lane);
+    else if constexpr (C::ARROW) search = -arrow_solve<C>(a, lt, dinv, grad, lane);
     else search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
     search = dofl ? search : 0.0f;
     PROF(PS_HESS)
@@ -569,6 +575,10 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
     const float dinv_m = rowchol_factor<C, true>(s.M, 0.0f, a, lt, s.scratch_a(), lane);
     a0 = rowchol_solve<C>(a, lt, dinv_m, fs, lane);
     a0 = lane < C::NV ? a0 : 0.0f;
+  } else if constexpr (C::ARROW) {
+    const float dinv_m = arrow_factor<C>(s.M, 0.0f, a, lt, s.scratch_a(), lane);
+    a0 = arrow_solve<C>(a, lt, dinv_m, fs, lane);
+    a0 = lane < C::NV ? a0 : 0.0f;
   } else {
 #pragma unroll
     for (int j = 0; j < C::NV; ++j) a[j] = Mrow[j];        // entries j > lane are never consumed by chol_factor
@@ -650,6 +660,12 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
       const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
       const float dinv_i = rowchol_factor<C, true, true>(s.M, dd, a, lt, s.scratch_a(), lane);
       qacc = rowchol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane);
+      qacc = lane < C::NV ? qacc : 0.0f;
+    } else if constexpr (C::ARROW) {
+      const int dl = arrow_dof<C>(lane);
+      const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
+      const float dinv_i = arrow_factor<C, true>(s.M, dd, a, lt, s.scratch_a(), lane);
+      qacc = arrow_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane);
       qacc = lane < C::NV ? qacc : 0.0f;
     } else {
     float dd = lane < C::NV ? m.timestep * s.damp[lane] : 0.0f;

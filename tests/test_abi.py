@@ -110,3 +110,26 @@ def test_malformed_blobs_are_refused(lib, cube_model):
     # (5) a name without terminator
     b = bytearray(blob); b[16:16 + 40] = b"a" * 40
     assert ok(b) == -1
+
+
+def test_go2_model_create_checks_the_block_arrow_structure(lib):
+    """The Go2 kernels factor M and H in block-arrow form (trunk of 6 dofs, legs of 3 that couple only through the trunk):
+    rsr_model_create accepts the shipped model and refuses one whose body chains or contact pairs tie two legs together."""
+    import numpy as np
+    from rsr_mjx_amd.envs import config, go2
+    from rsr_mjx_amd.model import model_fields, pack_blob
+    env = go2.load("Go2JoystickFlatTerrain")
+    f = model_fields(env.sys)
+    f.update(config.go2_env_fields(env.sys, env._config, 1000, True))
+    h = C.c_void_p()
+    create = lambda fields: (lambda b: lib.rsr_model_create(C.create_string_buffer(b, len(b)), len(b), C.byref(h)))(pack_blob(fields))
+    assert create(f) == 0
+    lib.rsr_model_destroy(h)
+    bad = dict(f); m1 = np.array(f["pair_mask1"]).copy()
+    m1[0] = int(m1[0]) | (7 << 6) | (7 << 9)                     # a contact pair whose chain holds the dofs of two legs
+    bad["pair_mask1"] = m1
+    assert create(bad) == -2 and b"legs" in lib.rsr_last_error()
+    bad = dict(f); bm = np.array(f["body_dofmask"]).copy()
+    bm[-1] = int(bm[-1]) | (7 << 6)                               # the last calf's chain also runs through the first leg
+    bad["body_dofmask"] = bm
+    assert create(bad) == -2
