@@ -1237,6 +1237,7 @@ static lspoint ls_point(const odata *d, const sctx *c, real alpha, const real *j
   return p;
 }
 
+static int g_ls_trace = -1;      /* RSR_LS_TRACE=1: the bracket of every line-search iteration on stderr (read once) */
 static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad) {
   int nv = m->nv;
   real snorm = 0, mv[NV_MAX];
@@ -1281,6 +1282,8 @@ static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad)
         if (hist_lo[(it - P) % LS_HIST] == lo.alpha && hist_hi[(it - P) % LS_HIST] == hi.alpha) { cap = it + (m->ls_iterations - it) % P; if (getenv("RSR_LS_TRACE")) fprintf(stderr, "cycle P=%d at it=%d\n", P, it); break; }
       hist_lo[it % LS_HIST] = lo.alpha; hist_hi[it % LS_HIST] = hi.alpha;
     }
+    if (g_ls_trace < 0) g_ls_trace = getenv("RSR_LS_TRACE") != NULL;
+    if (g_ls_trace) fprintf(stderr, "  ls it %d lo a=%.9g d0=%.6g c=%.9g | hi a=%.9g d0=%.6g c=%.9g | p0 d0=%.6g d1=%.6g c=%.9g\n", it, (double)lo.alpha, (double)lo.deriv0, (double)lo.cost, (double)hi.alpha, (double)hi.deriv0, (double)hi.cost, (double)p0.deriv0, (double)p0.deriv1, (double)p0.cost);
     int done = it >= cap;
     done |= !swap;
     real tol_lo = gtol, tol_hi = gtol;

@@ -133,3 +133,94 @@ def test_line_search_switches(cube_model, tshape_model, oracle_mod):
             assert np.quantile(err, 0.9) <= 1e-5, (kind, float(np.quantile(err, 0.9)))
         finally:
             orc.set_ls_rule(0); orc.set_ls_cycle(False)
+
+
+def test_standing_go2_foot_forces_match_the_row_weight_formula(go2_model, oracle_mod):
+    """The same closed form on the condim-3 path (Go2 feet: spheres on the floor, four pyramid rows per contact,
+    go2_mjx_feetonly.xml): the robot left standing on its home pose comes to rest on four contacts whose rows carry
+    f = D k imp |r|, D = imp / (w (1 - imp)), w = (t + mu^2 t) 2 mu^2 / impratio; the four edges of a contact add up to 4 f along
+    the normal, and the four feet together carry the robot's weight."""
+    from conftest import make_go2_blob
+    from rsr_mjx_amd import prng
+    A = go2_model.arrays
+    orc = oracle_mod.Oracle(make_go2_blob(go2_model), "f64")
+    st = orc.new_state(1)
+    orc.reset(st, prng.split(prng.PRNGKey(0), 1))
+    for _ in range(150):                                          # 3 s on the home pose
+        orc.step(st, np.zeros((1, 12), dtype=np.float32))
+    assert np.abs(st["qvel"][0]).max() < 2e-2, "the robot has come to rest"
+    qpos = st["qpos"][0].astype(np.float64)
+    orc.forward(qpos, np.zeros(go2_model.nv), st["ctrl"][0].astype(np.float64), st["qacc_warmstart"][0].astype(np.float64))
+    con = orc.get("contacts").reshape(-1, 10)
+    con = con[con[:, 0] < 0]                                      # penetrating
+    assert len(con) == 4 and len(set(con[:, 9].astype(int))) == 4, con
+    f = orc.get("efc_force"); nefc = len(f)
+    J = orc.get("efc_J").reshape(nefc, -1)
+    total_mass = float(A["body_mass"].sum())
+    assert abs(float(J[:, 2] @ f) - total_mass * 9.81) <= 0.01 * total_mass * 9.81      # dof 2: world z of the floating base
+    dt = float(A["opt_timestep"][0])
+    rows0 = nefc - 4 * len(con)                                   # the pyramid rows are the last 4 per contact, in contact order
+    # contacts are listed in the order of their constraint rows (pair order)
+    order = np.argsort(con[:, 9], kind="stable")
+    carried = 0.0
+    for slot, ci in enumerate(order):
+        c = con[ci]; pair = int(c[9])
+        g1, g2 = int(A["pair_geom1"][pair]), int(A["pair_geom2"][pair])
+        b1, b2 = int(A["geom_bodyid"][g1]), int(A["geom_bodyid"][g2])
+        solref, solimp = A["pair_solref"][pair].astype(np.float64), A["pair_solimp"][pair].astype(np.float64)
+        margin = float(A["pair_margin"][pair] - A["pair_gap"][pair])
+        # contact friction: the higher-priority geom's, else the maximum (the floor has priority 1 in the scene)
+        p1, p2 = int(A["geom_priority"][g1]), int(A["geom_priority"][g2])
+        mu = float(A["geom_friction"][g1][0] if p1 > p2 else (A["geom_friction"][g2][0] if p2 > p1 else max(A["geom_friction"][g1][0], A["geom_friction"][g2][0])))
+        t = float(A["body_invweight0"][b1][0] + A["body_invweight0"][b2][0])
+        w = (t + mu * mu * t) * 2.0 * mu * mu / float(A["opt_impratio"][0])
+        timeconst, dampratio = max(solref[0], 2 * dt), solref[1]
+        dmin, dmax, width, mid, power = solimp
+        k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio)
+        r = abs(margin - c[0])
+        x = r / width
+        y = 1.0 if x >= 1 else (x ** power / mid ** (power - 1) if x <= mid else 1 - (1 - x) ** power / (1 - mid) ** (power - 1))
+        imp = min(max(dmin + y * (dmax - dmin), 1e-4), 0.9999)
+        per_row = (imp / (w * (1.0 - imp))) * k * imp * r
+        rows = f[rows0 + 4 * slot: rows0 + 4 * slot + 4]
+        # at rest the four edges carry the same force up to the (small) tangential load of the stance
+        assert abs(rows.sum() - 4.0 * per_row) <= 0.02 * 4.0 * per_row, (slot, rows, per_row)
+        carried += rows.sum()
+    assert abs(carried - total_mass * 9.81) <= 0.02 * total_mass * 9.81
+
+
+def test_box_slides_with_the_coulomb_acceleration(cube_model, oracle_mod):
+    """Friction saturation by hand: with gravity tilted by theta about x (equivalent to tilting the table), the 0.5 kg box on
+    the table (sliding friction set to mu = 0.3: the model's own mu = 1 would tip the cube before it slides) stays put while
+    tan(theta) < mu and starts to slide along y with a = g (sin(theta) - mu cos(theta)) beyond it.  The pyramid's edges lie
+    along the contact frame's axes, so along an axis the pyramidal cone carries exactly mu N.  Only the first env-steps are
+    compared: a box sliding on four soft corner contacts starts to rock after ~60 ms (and the restated MJX solver, whose line
+    search can stall on the friction-loss kinks of the arm's rows, then leaves the solve early: DESIGN.md 2)."""
+    import copy
+    from rsr_mjx_amd import prng
+    A = cube_model.arrays
+    mu, g = 0.3, 9.81
+
+    def box_velocity_y(tan_theta, steps):
+        m = copy.copy(cube_model); m.arrays = dict(cube_model.arrays)
+        fr = np.array(A["geom_friction"]).copy(); fr[:, 0] = mu
+        m.arrays["geom_friction"] = fr
+        th = np.arctan(tan_theta)
+        m.arrays["opt_gravity"] = np.array([0.0, g * np.sin(th), -g * np.cos(th)], dtype=A["opt_gravity"].dtype)
+        orc = oracle_mod.Oracle(make_blob(m), "f64")
+        st = orc.new_state(1)
+        orc.reset(st, prng.split(prng.PRNGKey(0), 1))
+        st["qpos"][0][18:22] = [1, 0, 0, 0]; st["qpos"][0][17] = 0.8199; st["qvel"][0][14:20] = 0       # the box level and at rest
+        out = []
+        for _ in range(steps):
+            orc.step(st, np.zeros((1, 5), dtype=np.float32))
+            out.append(float(st["qvel"][0][15]))                  # dof 15: y translation of the box's free joint (dofs 14..19)
+        return np.array(out), th
+
+    dt_env = float(A["opt_timestep"][0]) * 4                       # 4 substeps per env-step
+    v, th = box_velocity_y(0.5 * mu, 6)                            # below the threshold: soft-constraint creep, no acceleration
+    assert np.abs(v).max() < 2e-3 and np.abs(np.diff(v)).max() / dt_env < 0.02, v
+    v, th = box_velocity_y(1.5 * mu, 4)                            # above it: the Coulomb acceleration
+    acc = np.diff(np.concatenate([[0.0], v])) / dt_env
+    want = g * (np.sin(th) - mu * np.cos(th))
+    assert np.abs(acc[1:] - want).max() <= 0.04 * want and acc.mean() <= want, (acc, want)
