@@ -143,7 +143,7 @@ struct StepArgs {
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
           int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false,
-          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false, bool ARROW_ = false>
+          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false, bool ARROW_ = false, int TREE1_ = 0, int TREE2_ = 0>
 struct Dims {
   // LDS diet of the single-iteration models (Go2: one Hessian per substep, explicit Euler): the transpose / exchange scratch T
   // has no storage of its own -- before the solve it is the dead part of phase A (cinert .. cfrcsum), from the Hessian on it
@@ -184,6 +184,18 @@ struct Dims {
   static constexpr int ANT = 6, ALEGN = 3, ALEGS = ARROW_ ? (NV_ - 6) / 3 : 0;
   static_assert(!ARROW_ || (NV_ == 6 + 3 * ((NV_ - 6) / 3) && (NV_ - 6) / 3 == 4 && !ROWCHOL), "block-arrow layout: 6 trunk dofs + 4 legs of 3");
   static constexpr int NCH = ROWCHOL ? NA : (ARROW_ ? 9 : NV_);
+  // Kinematic trees of the Airbot models (dof ranges [0, TREE1), [TREE1, TREE2), [TREE2, NV); checked on the host): the arm, and one
+  // or two free bodies.  The mass matrix never couples them, and the Hessian couples two of them only while a contact pair
+  // joins them (the arm pushing the object): otherwise each tree is factored in a 16-lane DPP row of its own, all rows in the same
+  // instructions -- max(tree size) pivots instead of NA.  Skipping the coupling steps changes nothing in the arithmetic of the
+  // coupled factorisation (they subtract 0 * x), so both layouts give the same bits.
+  static constexpr int TREE1 = TREE1_, TREE2 = TREE2_;
+  static constexpr bool ROWTREE = ROWCHOL && TREE1_ > 0;
+  static constexpr int tree_of(int dof) { return (dof >= TREE1_) + (dof >= TREE2_); }
+  static constexpr int tree_base(int t) { return t == 0 ? 0 : (t == 1 ? TREE1_ : TREE2_); }
+  static constexpr int tree_size(int t) { return t == 0 ? TREE1_ : (t == 1 ? TREE2_ - TREE1_ : NV_ - TREE2_); }
+  static constexpr int NCT = TREE1_ > TREE2_ - TREE1_ ? (TREE1_ > NV_ - TREE2_ ? TREE1_ : NV_ - TREE2_) : (TREE2_ - TREE1_ > NV_ - TREE2_ ? TREE2_ - TREE1_ : NV_ - TREE2_);
+  static_assert(!ROWTREE || (NCT <= NCH && NCT <= 16 && TREE2_ >= TREE1_ && TREE2_ <= NV_), "tree rows");
   static constexpr int dof_of_col_a(int c) { return c < ISO0_ ? c : c + NISO; }      // block A column -> dof
   static constexpr int dof_of_col_b(int c) { return ISO0_ + c; }                     // block B column -> dof
   static constexpr bool coupled(int i, int j) { return (i >= ISO0_ && i < ISO1_) == (j >= ISO0_ && j < ISO1_); }
@@ -446,6 +458,7 @@ struct Smem {
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
+  int trees_joined;          // Dims::ROWTREE: a contact pair of this substep joins two kinematic trees (the Hessian needs the coupled layout)
   int lim_jnt[C::NL > 0 ? C::NL : 1];
   // dof of every friction / limit row (their Jacobian row is a single +-1 there) and the Hessian's diagonal accumulator
   int sdof[C::NSP + 1];
@@ -965,6 +978,81 @@ __device__ __forceinline__ float rowchol_solve(const float (&a)[C::NCH], const f
   x *= dinv;
   static_for<0, C::NCH>([&](auto kc) { constexpr int k = C::NCH - 1 - decltype(kc)::value; fmac_self_bcast<k>(x, lt[k]); });   // backward
   return __shfl(x, lane < C::NV ? rowchol_lane<C>(lane) : 0);
+}
+
+// =====================================================================================
+// One kinematic tree per DPP row (Dims::ROWTREE): lane (row t, pos p) holds row `p` of tree t's block, a[c] = H[base_t + p][base_t + c].
+// Used for the mass-matrix factorisations always, for the Hessian while no contact pair joins two trees.
+// =====================================================================================
+template <class C> __device__ __forceinline__ int rowtree_dof(int lane) {
+  const int t = lane >> 4, p = lane & 15;
+  return (t < 3 && p < C::tree_size(t < 3 ? t : 0)) ? C::tree_base(t) + p : -1;
+}
+template <class C> __device__ __forceinline__ int rowtree_lane(int dof) { return 16 * C::tree_of(dof) + dof - C::tree_base(C::tree_of(dof)); }
+template <class C, bool HAS_DIAG = false>
+__device__ __forceinline__ float rowtree_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
+  static_assert(C::ROWTREE, "per-tree factorisation");
+  constexpr int N = C::NCT;
+  const int t = lane >> 4, p = lane & 15, dofl = rowtree_dof<C>(lane);
+#pragma unroll
+  for (int c = 0; c < C::NCH; ++c) a[c] = 0.0f;
+  // one exec region per tree with compile-time column offsets (see rowchol_factor)
+  static_for<0, 3>([&](auto tc) {
+    constexpr int tt = decltype(tc)::value;
+    if constexpr (C::tree_size(tt) > 0) {
+      if (t == tt && p < C::tree_size(tt)) {
+        const float* row = src + (C::tree_base(tt) + p) * C::LD + C::tree_base(tt);
+#pragma unroll
+        for (int c = 0; c < C::tree_size(tt); ++c) a[c] = row[c];
+      }
+    }
+  });
+  if constexpr (HAS_DIAG) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) if (c == p) a[c] += diag;            // (diag is zero for lanes outside the trees)
+  }
+  float dinv = 0.0f;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    float piv = row_bcast<k>(a[k]);
+    piv = piv > 0.0f ? piv : RSR_MINVAL;
+    float rcp = __builtin_amdgcn_rcpf(piv);
+    rcp = rcp + rcp * (1.0f - piv * rcp);
+    if (p == k) dinv = rcp;
+    const float u = a[k];
+    a[k] = (p > k) ? u * rcp : 0.0f;
+    const float lik = a[k];
+    static_for<k + 1, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j == k + 1) fmac_row_bcast<j, true>(a[j], u, lik); else fmac_row_bcast<j, false>(a[j], u, lik);
+    });
+  });
+  // transpose through LDS, per row: T[t][c][p] = a[c]; lt[k] = L[k][p] = a[p] of lane (t, k)
+  if (t < 3 && p < N) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) T[(t * N + c) * N + p] = a[c];
+  }
+  WSYNC();
+#pragma unroll
+  for (int k = 0; k < C::NCH; ++k) lt[k] = 0.0f;
+  if (t < 3 && p < N) {
+    const float* col = &T[(t * N + p) * N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) lt[k] = col[k];
+  }
+  WSYNC();
+  return dofl >= 0 ? dinv : 0.0f;
+}
+template <class C>
+__device__ __forceinline__ float rowtree_solve(const float (&a)[C::NCH], const float (&lt)[C::NCH], float dinv, float b, int lane) {
+  constexpr int N = C::NCT;
+  const int dofl = rowtree_dof<C>(lane);
+  float x = __shfl(b, dofl >= 0 ? dofl : 0);
+  x = dofl >= 0 ? x : 0.0f;
+  static_for<0, N>([&](auto kc) { constexpr int k = decltype(kc)::value; fmac_self_bcast<k>(x, a[k]); });
+  x *= dinv;
+  static_for<0, N>([&](auto kc) { constexpr int k = N - 1 - decltype(kc)::value; fmac_self_bcast<k>(x, lt[k]); });
+  return __shfl(x, lane < C::NV ? rowtree_lane<C>(lane) : 0);
 }
 
 // =====================================================================================
@@ -1760,6 +1848,14 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   if (lane < ncon) {
     int* t = &ctab[8 * lane];
     t[0] = ct3.x; t[1] = ct3.y; t[2] = ct3.z; t[3] = ct3.w; t[4] = ct0.x; t[5] = ct0.y; t[6] = ct2.w;
+  }
+  if constexpr (C::ROWTREE) {
+    // does a contact pair of this substep join two kinematic trees?  (equality rows stay inside a tree: checked on the host)
+    constexpr unsigned T0 = (1u << C::TREE1) - 1u, T01 = (1u << C::TREE2) - 1u, TALL = C::NV >= 32 ? 0xFFFFFFFFu : (1u << C::NV) - 1u;
+    const unsigned dm = lane < ncon ? (unsigned)(ct3.x | ct3.y) : 0u;
+    const int touched = ((dm & T0) != 0u) + ((dm & (T01 & ~T0)) != 0u) + ((dm & (TALL & ~T01)) != 0u);
+    const bool joined = __ballot(touched >= 2) != 0ull;
+    if (lane == 0) s.trees_joined = joined ? 1 : 0;
   }
   WSYNC();
   // equality e = lane (joint coupling): dif = qpos[j2] - qpos0[j2], polynomial data[0..4]

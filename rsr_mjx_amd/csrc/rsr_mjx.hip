@@ -19,12 +19,14 @@ namespace rsr {
 #define RSR_CUBE_NCON 24
 #endif
 using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_NCON, /*OBS*/ 23, /*NMET*/ 3, 0, 0, 4, 0,
-                      /*ISO: the target body's free joint, dofs 8..13*/ 8, 14>;
+                      /*ISO: the target body's free joint, dofs 8..13*/ 8, 14, false, false, false, /*NGA*/ 23, false, false,
+                      /*TREE1, TREE2: arm | target | cube*/ 8, 14>;
 // Airbot T-shape: nq 15, nv 14, njnt 9, ngeom 25, nsite 3, npair 60; 4 env geoms at env_ids[5..8]
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
                      /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true, /*ARROW*/ true>;
-using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5>;
+using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5, /*CONDIM*/ 4, 0, 0, 0, false, false, false,
+                        /*NGA*/ 25, false, false, /*TREE1, TREE2: arm | T block*/ 8, 14>;
 
 // env_ids layout (rsr_mjx_amd/envs/config.py)
 enum { ID_CUBE = 0, ID_TARGET = 1, ID_SITE = 2, ID_BOXQ = 3, ID_SITEQ = 4, ID_FINGERQ = 5, ID_JOINTQ = 6 };
@@ -1301,6 +1303,27 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
       okg = f1 && f2;
     }
     if (!okg) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: geom_slot_ids do not match the kernel's geom slots (Dims::NGA) or miss a pair geom"); }
+  }
+  if (d.env_kind != rsr::ENV_GO2) {
+    // the Airbot kernels factor one kinematic tree per DPP row (Dims::ROWTREE): dof ranges [0, TREE1), [TREE1, TREE2), [TREE2, nv)
+    // must be separate trees -- no body chain and no equality constraint may straddle them
+    const int t1 = d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::TREE1 : rsr::CubeDims::TREE1;
+    const int t2 = d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::TREE2 : rsr::CubeDims::TREE2;
+    auto trees_of = [&](unsigned mask) {
+      const unsigned m0 = (1u << t1) - 1u, m01 = (1u << t2) - 1u;
+      return ((mask & m0) != 0u) + ((mask & (m01 & ~m0)) != 0u) + ((mask & ~m01) != 0u);
+    };
+    int nbm = 0, neq = 0;
+    const unsigned* bm = static_cast<const unsigned*>(m->find("body_dofmask", &nbm));
+    bool okt = bm != nullptr;
+    for (int b = 0; okt && b < nbm; ++b) okt = trees_of(bm[b]) <= 1;
+    const int* e1 = static_cast<const int*>(m->find("eq_obj1id", &neq)); const int* e2 = static_cast<const int*>(m->find("eq_obj2id"));
+    const int* jd = static_cast<const int*>(m->find("jnt_dofadr"));
+    for (int q = 0; okt && e1 && e2 && jd && q < neq; ++q) {
+      const bool j1 = e1[q] >= 0 && e1[q] < d.njnt, j2 = e2[q] >= 0 && e2[q] < d.njnt;
+      if (j1 && j2) okt = trees_of((1u << jd[e1[q]]) | (1u << jd[e2[q]])) <= 1;
+    }
+    if (!okt) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the Airbot kernels need the arm and the free bodies as separate kinematic trees over fixed dof ranges"); }
   }
   if (d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::ARROW) {
     // the Go2 kernels factor M and H in block-arrow form (Dims::ARROW): dofs 0..5 are the trunk, every further group of three dofs

@@ -232,7 +232,7 @@ __device__ __forceinline__ float jt_force(Smem<C>& s, int lane, int nefc, int nb
 //    all contacts are visited (an all-inactive pyramid has W = 0), which keeps the loop free of index loads.
 template <class C>
 __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, int nbase, const float (&hw)[C::NCHUNK],
-                                               float (&a)[C::NCH], float (&lt)[C::NCH] PROF_ARG) {
+                                               float (&a)[C::NCH], float (&lt)[C::NCH], bool joined PROF_ARG) {
   constexpr int NBLK = (C::NV + 1) / 2;
   static_assert(NBLK * (NBLK + 1) / 2 <= 64, "Hessian blocks exceed one wave");
   static_assert(C::NV % 2 == 0, "2x2 Hessian blocking assumes an even dof count");
@@ -305,6 +305,14 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     // the row-blocked factorisation reads its (permuted) rows from T and later writes its transpose to T: one wave, LDS
     // operations in order, and the rows are in registers (waited for) before the factor loop that precedes the writes
     PROF(PS_H_XCHG)
+    if constexpr (C::ROWTREE) {
+      if (!joined) {                                  // no contact joins two trees: one tree per DPP row
+        const float dinv = rowtree_factor<C>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
+        if constexpr (!C::TALIAS && !C::TTAIL) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }
+        PROF(PS_H_CHOL)
+        return dinv;
+      }
+    }
     const float dinv = rowchol_factor<C, false>(s.scratch_b(), 0.0f, a, lt, s.scratch_b(), lane);
     if constexpr (!C::TALIAS && !C::TTAIL) { if (lane < 4) s.bval[C::NBASE + lane] = 0.0f; }      // the null row's value (the exchange ran over it)
     PROF(PS_H_CHOL)
@@ -394,6 +402,8 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   PROF(PS_S_JTF)
   // the solver's options, fetched once: read where they are used, each is a scalar load from the model struct with its own
   // wait (the struct is passed by pointer so that its ~180 pointers do not sit in SGPRs), a dozen per Newton iteration
+  bool joined = true;
+  if constexpr (C::ROWTREE) joined = uniform_i(s.trees_joined) != 0;
   const int opt_iterations = m.iterations, opt_ls_iterations = m.ls_iterations;
   const float opt_tolerance = m.tolerance, opt_ls_tolerance = m.ls_tolerance, opt_meaninertia = m.meaninertia;
   const float scale = 1.0f / (opt_meaninertia * (float)(C::NV > 1 ? C::NV : 1));
@@ -423,13 +433,14 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
 #pragma unroll
     for (int ch = 0; ch < C::NCHUNK; ++ch) changed |= hw[ch] != hw_fact[ch];
     if (uniform_i(__ballot(changed) != 0ull)) {
-      dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt PROF_PASS);
+      dinv = hessian_factor<C>(s, lane, nefc, nbase, hw, a, lt, joined PROF_PASS);
 #pragma unroll
       for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = hw[ch];
       have_factor = true;
     }
     float search;
-    if constexpr (C::ROWCHOL) search = -rowchol_solve<C>(a, lt, dinv, grad, lane);
+    if constexpr (C::ROWTREE) search = joined ? -rowchol_solve<C>(a, lt, dinv, grad, lane) : -rowtree_solve<C>(a, lt, dinv, grad, lane);
+    else if constexpr (C::ROWCHOL) search = -rowchol_solve<C>(a, lt, dinv, grad, lane);
     else if constexpr (C::ARROW) search = -arrow_solve<C>(a, lt, dinv, grad, lane);
     else search = dofl ? -chol_solve<C>(a, lt, dinv, grad, lane) : 0.0f;
     search = dofl ? search : 0.0f;
@@ -571,7 +582,11 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   // qacc_smooth = M^-1 qfrc_smooth
   float a[C::NCH], lt[C::NCH];
   float a0;
-  if constexpr (C::ROWCHOL) {
+  if constexpr (C::ROWTREE) {
+    const float dinv_m = rowtree_factor<C>(s.M, 0.0f, a, lt, s.scratch_a(), lane);
+    a0 = rowtree_solve<C>(a, lt, dinv_m, fs, lane);
+    a0 = lane < C::NV ? a0 : 0.0f;
+  } else if constexpr (C::ROWCHOL) {
     const float dinv_m = rowchol_factor<C, true>(s.M, 0.0f, a, lt, s.scratch_a(), lane);
     a0 = rowchol_solve<C>(a, lt, dinv_m, fs, lane);
     a0 = lane < C::NV ? a0 : 0.0f;
@@ -655,7 +670,13 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
   const bool implicit = implicit_integration<C>(m, s, lane);
   if (implicit) {
     float a[C::NCH], lt[C::NCH];
-    if constexpr (C::ROWCHOL) {
+    if constexpr (C::ROWTREE) {
+      const int dl = rowtree_dof<C>(lane);
+      const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
+      const float dinv_i = rowtree_factor<C, true>(s.M, dd, a, lt, s.scratch_a(), lane);
+      qacc = rowtree_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane);
+      qacc = lane < C::NV ? qacc : 0.0f;
+    } else if constexpr (C::ROWCHOL) {
       const int dl = rowchol_dof<C>(lane);
       const float dd = dl >= 0 ? m.timestep * s.damp[dl] : 0.0f;
       const float dinv_i = rowchol_factor<C, true, true>(s.M, dd, a, lt, s.scratch_a(), lane);

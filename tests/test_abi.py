@@ -133,3 +133,20 @@ def test_go2_model_create_checks_the_block_arrow_structure(lib):
     bm[-1] = int(bm[-1]) | (7 << 6)                               # the last calf's chain also runs through the first leg
     bad["body_dofmask"] = bm
     assert create(bad) == -2
+
+
+def test_airbot_model_create_checks_the_tree_ranges(lib, cube_model):
+    """The Airbot kernels factor one kinematic tree per DPP row (arm | target | cube over fixed dof ranges): a model whose body
+    chain straddles two ranges is refused."""
+    import numpy as np
+    from rsr_mjx_amd.envs import config
+    from rsr_mjx_amd.model import model_fields, pack_blob
+    f = model_fields(cube_model); f.update(config.cube_env_fields(cube_model))
+    h = C.c_void_p()
+    create = lambda fields: (lambda b: lib.rsr_model_create(C.create_string_buffer(b, len(b)), len(b), C.byref(h)))(pack_blob(fields))
+    assert create(f) == 0
+    lib.rsr_model_destroy(h)
+    bad = dict(f); bm = np.array(f["body_dofmask"]).copy()
+    bm[-1] = int(bm[-1]) | 1                                      # the last body's chain also runs through the arm's first dof
+    bad["body_dofmask"] = bm
+    assert create(bad) == -2 and b"trees" in lib.rsr_last_error()
