@@ -459,6 +459,9 @@ struct Smem {
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int trees_joined;          // Dims::ROWTREE: a contact pair of this substep joins two kinematic trees (the Hessian needs the coupled layout)
+  // Dims::ROWTREE, trees not joined: the contacts of each tree, in contact order (a block of the Hessian only visits its own tree's)
+  int tree_ncon[4];
+  alignas(8) unsigned char tree_con[(C::ROWTREE && C::tree_size(2) > 0) ? 3 * C::NCON : 8];
   int lim_jnt[C::NL > 0 ? C::NL : 1];
   // dof of every friction / limit row (their Jacobian row is a single +-1 there) and the Hessian's diagonal accumulator
   int sdof[C::NSP + 1];
@@ -1856,6 +1859,14 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
     const int touched = ((dm & T0) != 0u) + ((dm & (T01 & ~T0)) != 0u) + ((dm & (TALL & ~T01)) != 0u);
     const bool joined = __ballot(touched >= 2) != 0ull;
     if (lane == 0) s.trees_joined = joined ? 1 : 0;
+    const int mytree = (dm & T0) != 0u ? 0 : ((dm & (T01 & ~T0)) != 0u ? 1 : 2);
+    if constexpr (C::tree_size(2) > 0)             // (the per-tree contact walk of the Hessian is used by three-tree models only)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const unsigned long long in_t = __ballot(lane < ncon && mytree == t);
+      if (lane < ncon && mytree == t) s.tree_con[t * C::NCON + __popcll(in_t & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+      if (lane == 0) s.tree_ncon[t] = __popcll(in_t);
+    }
   }
   WSYNC();
   // equality e = lane (joint coupling): dif = qpos[j2] - qpos0[j2], polynomial data[0..4]

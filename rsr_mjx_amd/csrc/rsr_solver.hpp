@@ -275,7 +275,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
     h00 += a0 * b0; h01 += a0 * b1; h10 += a1 * b0; h11 += a1 * b1;
   }
   PROF(PS_H_SPARSE)
-  for (int c = 0; c < ncon; ++c) {
+  auto add_contact = [&](int c) {
     const float* B = &s.x.b.J[(rcon + C::NBC * c) * C::LDJ];
     const float* w = &s.wc[8 * c];
     float ni0 = B[i0], ni1 = B[i0 + 1], nj0 = B[j0], nj1 = B[j0 + 1];
@@ -290,6 +290,30 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
       a00 += di0 * u0d; a01 += di0 * u1d; a10 += di1 * u0d; a11 += di1 * u1d;
     }
     h00 += ni0 * u0n + a00; h01 += ni0 * u1n + a01; h10 += ni1 * u0n + a10; h11 += ni1 * u1n + a11;
+  };
+  bool by_tree = false;
+  if constexpr (C::ROWTREE && C::tree_size(2) > 0) by_tree = !joined;      // (two trees, one of them the arm with few contacts: no gain, measured)
+  if (by_tree) {
+    // no contact joins two trees: a block lies in one tree (or between two, and is zero) and only that tree's contacts touch it,
+    // so the lanes of the three trees walk their own contact lists side by side: max(contacts per tree) trips instead of ncon.
+    // Within a block the contacts are added in the same order as in the full walk, which only adds zeros in between.
+    if constexpr (C::ROWTREE) {
+      const int ti = C::tree_of(i0), tj = C::tree_of(j0);
+      const int n0 = s.tree_ncon[0], n1 = s.tree_ncon[1], n2 = s.tree_ncon[2];
+      const int nmine = (blk && ti == tj) ? (ti == 0 ? n0 : (ti == 1 ? n1 : n2)) : 0;
+      const int nmax = n0 > n1 ? (n0 > n2 ? n0 : n2) : (n1 > n2 ? n1 : n2);
+      const unsigned char* list = &s.tree_con[ti * C::NCON];
+      // the first eight entries of the list in two registers: no index load inside the loop for the usual case
+      static_assert(C::NCON % 8 == 0, "tree contact lists are read as 8-byte words");
+      const uint2 head = *reinterpret_cast<const uint2*>(list);
+      for (int q = 0; q < nmax; ++q) {
+        const unsigned word = q < 4 ? head.x : head.y;
+        const int c = q < 8 ? (int)((word >> (8 * (q & 3))) & 0xFFu) : (int)list[q < C::NCON ? q : 0];
+        if (q < nmine) add_contact(c);
+      }
+    }
+  } else {
+    for (int c = 0; c < ncon; ++c) add_contact(c);
   }
   PROF(PS_H_CONTACT)
   if (blk) {
