@@ -1312,10 +1312,10 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
     if (sv > best_face) { best_face = sv; face_code = 3 + j; }
   }
   if (sep) return;
-  // edge axes; the winning pair of edges is kept as vectors so that nothing is indexed dynamically afterwards
+  // edge axes: only the index pair of the best axis is tracked in the loop; its edge geometry (the closest edges' centres, nine
+  // cross products and sign tests when done per candidate) is built once, after the loop, and only if an edge contact wins
   float best_edge = -1e30f; bool have_edge = false;
-  V3 eai = v3(0, 0, 0), ebj = v3(0, 0, 0); float ea_half = 0, eb_half = 0;
-  V3 ea_c = pa, eb_c = pb;
+  int wi = 0, wj = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
@@ -1329,29 +1329,35 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
       float sv = (fabsf(tl) - (ra + rb)) / sqrtf(fmaxf(l2, 1e-12f));
       bool ok = !(l2 < 1e-6f);
       sep |= ok && sv > 0.0f;
-      if (ok && sv > best_edge) {
-        best_edge = sv; have_edge = true; eai = A[i]; ebj = B[j]; ea_half = sa[i]; eb_half = sb[j];
-        V3 L = cross(A[i], B[j]);
-        if (dot(L, dp) < 0.0f) L = L * -1.0f;
-        ea_c = pa + A[i1] * ((dot(L, A[i1]) > 0 ? 1.0f : -1.0f) * sa[i1]) + A[i2] * ((dot(L, A[i2]) > 0 ? 1.0f : -1.0f) * sa[i2]);
-        eb_c = pb + B[j1] * ((dot(L, B[j1]) > 0 ? -1.0f : 1.0f) * sb[j1]) + B[j2] * ((dot(L, B[j2]) > 0 ? -1.0f : 1.0f) * sb[j2]);
-      }
+      if (ok && sv > best_edge) { best_edge = sv; have_edge = true; wi = i; wj = j; }
     }
   }
   if (sep) return;
   if (have_edge && (best_edge > 0.95f * best_face + 1e-6f)) {
+    // the winning edges, picked with selects (no dynamic indexing of the register arrays)
+    auto pick = [](const V3 (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+    auto pickf = [](const float (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+    const int wi1 = wi == 2 ? 0 : wi + 1, wi2 = wi == 0 ? 2 : wi - 1, wj1 = wj == 2 ? 0 : wj + 1, wj2 = wj == 0 ? 2 : wj - 1;
+    const V3 eai = pick(A, wi), ebj = pick(B, wj), Ai1 = pick(A, wi1), Ai2 = pick(A, wi2), Bj1 = pick(B, wj1), Bj2 = pick(B, wj2);
+    const float ea_half = pickf(sa, wi), eb_half = pickf(sb, wj), sai1 = pickf(sa, wi1), sai2 = pickf(sa, wi2), sbj1 = pickf(sb, wj1), sbj2 = pickf(sb, wj2);
     V3 L = cross(eai, ebj);
-    L = L * (1.0f / sqrtf(dot(L, L)));
-    if (dot(L, dp) < 0.0f) L = L * -1.0f;
-    V3 r = eb_c - ea_c;
-    float uab = dot(eai, ebj), q1 = dot(eai, r), q2 = -dot(ebj, r), den = 1.0f - uab * uab;
-    float sp = clampf((q1 + uab * q2) / den, -ea_half, ea_half);
-    float up = clampf((uab * q1 + q2) / den, -eb_half, eb_half);
-    V3 qa = ea_c + eai * sp, qb = eb_c + ebj * up;
-    float dist = dot(qb - qa, L);
-    if (!(dist < 0.0f)) return;
-    out.n = L; out.dist[0] = dist; out.pos[0] = (qa + qb) * 0.5f; out.cnt = 1;
-    return;
+    {
+      V3 Ls = L;
+      if (dot(Ls, dp) < 0.0f) Ls = Ls * -1.0f;
+      const V3 ea_c = pa + Ai1 * ((dot(Ls, Ai1) > 0 ? 1.0f : -1.0f) * sai1) + Ai2 * ((dot(Ls, Ai2) > 0 ? 1.0f : -1.0f) * sai2);
+      const V3 eb_c = pb + Bj1 * ((dot(Ls, Bj1) > 0 ? -1.0f : 1.0f) * sbj1) + Bj2 * ((dot(Ls, Bj2) > 0 ? -1.0f : 1.0f) * sbj2);
+      L = L * (1.0f / sqrtf(dot(L, L)));
+      if (dot(L, dp) < 0.0f) L = L * -1.0f;
+      V3 r = eb_c - ea_c;
+      float uab = dot(eai, ebj), q1 = dot(eai, r), q2 = -dot(ebj, r), den = 1.0f - uab * uab;
+      float sp = clampf((q1 + uab * q2) / den, -ea_half, ea_half);
+      float up = clampf((uab * q1 + q2) / den, -eb_half, eb_half);
+      V3 qa = ea_c + eai * sp, qb = eb_c + ebj * up;
+      float dist = dot(qb - qa, L);
+      if (!(dist < 0.0f)) return;
+      out.n = L; out.dist[0] = dist; out.pos[0] = (qa + qb) * 0.5f; out.cnt = 1;
+      return;
+    }
   }
   // face contact: reference box R, incident box Q; selections are done with compile-time indices + selects
   const bool ref_is_a = face_code < 3;
