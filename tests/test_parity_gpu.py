@@ -467,3 +467,51 @@ def test_contact_capacity_overflow_is_reported(setup, oracle_mod):
     assert np.isfinite(d).all() and d.max() <= 0.2, float(d.max())
     print(f"capacity overflow: dropped {stats[over, 3].tolist()} contacts; qpos distance to the uncapped oracle after one env-step: "
           f"max {d.max():.2e}, median {np.median(d):.2e}")
+
+
+@pytest.mark.gpu
+def test_arm_touching_the_cube_takes_the_coupled_factorisation(setup, oracle_mod):
+    """Dims::ROWTREE: while no contact joins two kinematic trees the Hessian is factored one tree per DPP row; a contact between
+    the arm and the cube switches to the coupled layout (0.4 % of the bench's env-steps, so random rollouts hardly test it).
+    Here the cube is slid towards the gripper in every env until the oracle reports the first arm-cube contact (penetration
+    below 2 mm: deep interpenetration is chaotic on both sides), and the step from there must land on the oracle."""
+    import torch
+    from rsr_mjx_amd.envs.airbot import AirbotPlayBase
+    from rsr_mjx_amd import prng
+    n = 64
+    env = AirbotPlayBase(device="cuda:0").batched(n, episode_length=1200, auto_reset=True)
+    orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    orc.set_ls_cycle(True); orc.set_ls_rule(2, 1.0)                       # the kernel's line-search rules
+    keys = prng.split(prng.PRNGKey(7), n)
+    st = orc.new_state(n); orc.reset(st, keys)
+    state = env.reset(keys)
+    cube_b = 13                                                            # body ids: arm 1..10, cube 13
+    st["qvel"][:] = 0; st["qacc_warmstart"][:] = 0
+
+    def arm_cube_contact(e):
+        orc.forward(st["qpos"][e].astype(np.float64), st["qvel"][e].astype(np.float64), st["ctrl"][e].astype(np.float64), st["qacc_warmstart"][e].astype(np.float64))
+        con = orc.get("contacts").reshape(-1, 10)
+        b1, b2 = con[:, 7].astype(int), con[:, 8].astype(int)
+        hit = (((b1 == cube_b) & (b2 >= 1) & (b2 <= 10)) | ((b2 == cube_b) & (b1 >= 1) & (b1 <= 10))) & (con[:, 0] < 0)
+        return bool(hit.any())
+
+    touching = 0
+    for e in range(n):
+        site = st["site_xpos"][e, 0].copy()
+        st["qpos"][e, 18:22] = [1, 0, 0, 0]
+        for d in np.arange(0.15, -0.002, -0.002):                          # from clear of the gripper towards the site, along -x
+            st["qpos"][e, 15:18] = [site[0] - d, site[1], 0.82]
+            if arm_cube_contact(e):
+                touching += 1
+                break
+    assert touching >= n // 2, f"only {touching} of {n} envs reach an arm-cube contact"
+    _push(env, st)
+    rng = np.random.default_rng(7)
+    act = np.clip(rng.normal(0, 1, (n, 5)), -1, 1).astype(np.float32)
+    orc.step(st, act)
+    env.step(state, torch.from_numpy(act).cuda())
+    torch.cuda.synchronize()
+    for k in ("qpos", "xpos", "obs", "reward"):
+        e = _scaled_err(_np(env, k, st[k]), st[k])
+        assert np.quantile(e, 0.9) <= 1e-4 and e.max() <= 2e-2, (k, float(np.quantile(e, 0.9)), float(e.max()))
+        print(f"arm-cube contact step, {k}: median {np.median(e):.1e} p90 {np.quantile(e, 0.9):.1e} max {e.max():.1e} ({touching} of {n} envs touching)")
