@@ -1335,8 +1335,11 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
   if (sep) return;
   if (have_edge && (best_edge > 0.95f * best_face + 1e-6f)) {
     // the winning edges, picked with selects (no dynamic indexing of the register arrays)
-    auto pick = [](const V3 (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
-    auto pickf = [](const float (&v)[3], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); };
+    // (the candidates pass through an empty asm as scalars: a select between elements of the register arrays would be rewritten
+    // into a load through a selected address, which puts the arrays -- and a store of every element per SAT -- into scratch)
+    auto sel3 = [](float a, float b, float c, int k) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); return k == 0 ? a : (k == 1 ? b : c); };
+    auto pick = [&](const V3 (&v)[3], int k) { return V3{sel3(v[0].x, v[1].x, v[2].x, k), sel3(v[0].y, v[1].y, v[2].y, k), sel3(v[0].z, v[1].z, v[2].z, k)}; };
+    auto pickf = [&](const float (&v)[3], int k) { return sel3(v[0], v[1], v[2], k); };
     const int wi1 = wi == 2 ? 0 : wi + 1, wi2 = wi == 0 ? 2 : wi - 1, wj1 = wj == 2 ? 0 : wj + 1, wj2 = wj == 0 ? 2 : wj - 1;
     const V3 eai = pick(A, wi), ebj = pick(B, wj), Ai1 = pick(A, wi1), Ai2 = pick(A, wi2), Bj1 = pick(B, wj1), Bj2 = pick(B, wj2);
     const float ea_half = pickf(sa, wi), eb_half = pickf(sb, wj), sai1 = pickf(sa, wi1), sai2 = pickf(sa, wi2), sbj1 = pickf(sb, wj1), sbj2 = pickf(sb, wj2);
