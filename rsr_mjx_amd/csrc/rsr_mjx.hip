@@ -69,23 +69,41 @@ __device__ __forceinline__ float uniform_from_bits(uint32_t b, float lo, float h
 template <class C>
 __device__ void load_overrides(const DModel& m, Smem<C>& s, const StepArgs& a, int e, int lane) {
   if (lane < 4) s.rw[C::NEFC + lane] = 0.0f;                 // zero weight of the null row
-  for (int t = lane; t < C::NGA * 3; t += 64) {               // friction of the geom slots (geoms of the contact pairs)
-    const int src = C::NGA == C::NG ? t : 3 * m.geom_slot_ids[t / 3] + t % 3;
-    s.fric[t] = a.dr_geom_friction ? a.dr_geom_friction[(size_t)e * C::NG * 3 + src] : m.geom_friction[src];
+  // Per-env leaf or the model's own: the source POINTER is selected, then every value is read in one batch of global loads and
+  // stored to LDS after one wait.  (A branch per leaf -- `dr ? dr[..] : m.x[..]` -- made each leaf's load wait on its own: up
+  // to nine global round trips in a row at the start of every work unit.)
+  auto src = [&](const float* dr, gp_f own, int per_env) { return dr ? (gp_f)(dr + (size_t)e * per_env) : own; };
+  const gp_f p_fric = src(a.dr_geom_friction, m.geom_friction, C::NG * 3), p_mass = src(a.dr_body_mass, m.body_mass, C::NB);
+  const gp_f p_damp = src(a.dr_dof_damping, m.dof_damping, C::NV), p_floss = src(a.dr_dof_frictionloss, m.dof_frictionloss, C::NV);
+  constexpr int NFR = (C::NGA * 3 + 63) / 64;
+  float v_fric[NFR];
+#pragma unroll
+  for (int k = 0; k < NFR; ++k) {                             // friction of the geom slots (geoms of the contact pairs)
+    const int t = lane + 64 * k, tt = t < C::NGA * 3 ? t : 0;
+    const int sidx = C::NGA == C::NG ? tt : 3 * m.geom_slot_ids[tt / 3] + tt % 3;
+    v_fric[k] = p_fric[sidx];
   }
-  if (lane < C::NB) s.mass[lane] = a.dr_body_mass ? a.dr_body_mass[(size_t)e * C::NB + lane] : m.body_mass[lane];
-  if (lane < C::NV) {
-    s.damp[lane] = a.dr_dof_damping ? a.dr_dof_damping[(size_t)e * C::NV + lane] : m.dof_damping[lane];
-    s.floss[lane] = a.dr_dof_frictionloss ? a.dr_dof_frictionloss[(size_t)e * C::NV + lane] : m.dof_frictionloss[lane];
-  }
+  const float v_mass = p_mass[lane < C::NB ? lane : 0];
+  const int dl = lane < C::NV ? lane : 0;
+  const float v_damp = p_damp[dl], v_floss = p_floss[dl];
+  float v_ipos[2] = {0, 0}, v_q0 = 0, v_arma = 0, v_gain = 0, v_bias = 0;
   if constexpr (C::DREX) {
-    if (lane < C::NB * 3) s.dx_ipos[lane] = a.dr_body_ipos ? a.dr_body_ipos[(size_t)e * C::NB * 3 + lane] : m.body_ipos[lane];
-    if (lane < C::NQ) s.dx_qpos0[lane] = a.dr_qpos0 ? a.dr_qpos0[(size_t)e * C::NQ + lane] : m.qpos0[lane];
-    if (lane < C::NV) s.dx_arma[lane] = a.dr_dof_armature ? a.dr_dof_armature[(size_t)e * C::NV + lane] : m.dof_armature[lane];
-    if (lane < C::NU * 3) {
-      s.dx_gain[lane] = a.dr_gainprm ? a.dr_gainprm[(size_t)e * C::NU * 3 + lane] : m.actuator_gainprm[lane];
-      s.dx_bias[lane] = a.dr_biasprm ? a.dr_biasprm[(size_t)e * C::NU * 3 + lane] : m.actuator_biasprm[lane];
-    }
+    static_assert(C::NB * 3 <= 64 && C::NQ <= 64 && C::NU * 3 <= 64, "one lane per extended leaf entry");
+    const gp_f p_ipos = src(a.dr_body_ipos, m.body_ipos, C::NB * 3), p_q0 = src(a.dr_qpos0, m.qpos0, C::NQ);
+    const gp_f p_arma = src(a.dr_dof_armature, m.dof_armature, C::NV);
+    const gp_f p_gain = src(a.dr_gainprm, m.actuator_gainprm, C::NU * 3), p_bias = src(a.dr_biasprm, m.actuator_biasprm, C::NU * 3);
+    v_ipos[0] = p_ipos[lane < C::NB * 3 ? lane : 0]; v_q0 = p_q0[lane < C::NQ ? lane : 0]; v_arma = p_arma[dl];
+    v_gain = p_gain[lane < C::NU * 3 ? lane : 0]; v_bias = p_bias[lane < C::NU * 3 ? lane : 0];
+  }
+#pragma unroll
+  for (int k = 0; k < NFR; ++k) { const int t = lane + 64 * k; if (t < C::NGA * 3) s.fric[t] = v_fric[k]; }
+  if (lane < C::NB) s.mass[lane] = v_mass;
+  if (lane < C::NV) { s.damp[lane] = v_damp; s.floss[lane] = v_floss; }
+  if constexpr (C::DREX) {
+    if (lane < C::NB * 3) s.dx_ipos[lane] = v_ipos[0];
+    if (lane < C::NQ) s.dx_qpos0[lane] = v_q0;
+    if (lane < C::NV) s.dx_arma[lane] = v_arma;
+    if (lane < C::NU * 3) { s.dx_gain[lane] = v_gain; s.dx_bias[lane] = v_bias; }
   }
 }
 
