@@ -30,6 +30,11 @@ if "--go2" in sys.argv:
     from rsr_mjx_amd.envs import go2
     env = go2.load("Go2JoystickFlatTerrain").batched(n, episode_length=1000, auto_reset=True)
     nu, astd = 12, 0.3
+elif "--tshape" in sys.argv:
+    from rsr_mjx_amd.envs.airbot import AirbotTShape
+    envdef = AirbotTShape()
+    env = envdef.batched(n, episode_length=1200, auto_reset=True)
+    nu, astd = 5, 1.0
 else:
     envdef = AirbotPlayBase()
     dr = domain_randomize(envdef.sys, prng.split(prng.PRNGKey(1), n))
