@@ -1861,6 +1861,15 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
     int* t = &ctab[8 * lane];
     t[0] = ct3.x; t[1] = ct3.y; t[2] = ct3.z; t[3] = ct3.w; t[4] = ct0.x; t[5] = ct0.y; t[6] = ct2.w;
   }
+  // the contact frame, once per contact (the base-row loop below visits a contact NV times and rebuilt it every time: two square
+  // roots and two divisions per visit): the normalised normal replaces the raw one in cnrm, the tangents go to s.rw (free
+  // until the Hessian; its last four words, the null row's weights, are not touched)
+  static_assert(6 * C::NCON <= C::NEFC, "contact tangents are staged in the row-weight array");
+  if (lane < ncon) {
+    V3 nn, t1, t2;
+    make_frame(ld3(&s.cnrm[3 * lane]), nn, t1, t2);
+    st3(&s.cnrm[3 * lane], nn); st3(&s.rw[6 * lane], t1); st3(&s.rw[6 * lane + 3], t2);
+  }
   if constexpr (C::ROWTREE) {
     // does a contact pair of this substep join two kinematic trees?  (equality rows stay inside a tree: checked on the host)
     constexpr unsigned T0 = (1u << C::TREE1) - 1u, T01 = (1u << C::TREE2) - 1u, TALL = C::NV >= 32 ? 0xFFFFFFFFu : (1u << C::NV) - 1u;
@@ -1902,8 +1911,7 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
     const int* ct = &ctab[8 * c];
     const unsigned mask1 = (unsigned)ct[0], mask2 = (unsigned)ct[1];
     const int body1 = ct[2], body2 = ct[3];
-    V3 pos = ld3(&s.cpos[3 * c]), n = ld3(&s.cnrm[3 * c]), t1, t2, nn;
-    make_frame(n, nn, t1, t2);
+    const V3 pos = ld3(&s.cpos[3 * c]), nn = ld3(&s.cnrm[3 * c]), t1 = ld3(&s.rw[6 * c]), t2 = ld3(&s.rw[6 * c + 3]);
     V3 ang = ld3(&s.cdof[6 * i]), lin = ld3(&s.cdof[6 * i + 3]);
     float in1 = ((mask1 >> i) & 1) ? 1.0f : 0.0f, in2 = ((mask2 >> i) & 1) ? 1.0f : 0.0f;
     V3 o1 = pos - ld3(&s.com[3 * body1]), o2 = pos - ld3(&s.com[3 * body2]);
