@@ -259,8 +259,16 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   }
   WSYNC();
   PROF(PS_H_PREP)
+  // block row of this lane in the packed lower triangle: the largest bi with bi (bi + 1) / 2 <= lane (closed form + fix-up
+  // instead of a counting loop of up to NBLK trips per Hessian)
   int bi = 0;
-  while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
+  if constexpr (C::ROWCHOL) {        // (measured: +0.9 % on the cube; the Go2 kernel is 2 % faster with the loop)
+    bi = (int)((__builtin_sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+    bi += ((bi + 1) * (bi + 2) / 2 <= lane) ? 1 : 0;
+    bi -= (bi * (bi + 1) / 2 > lane) ? 1 : 0;
+  } else {
+    while ((bi + 1) * (bi + 2) / 2 <= lane) ++bi;
+  }
   int bj = lane - bi * (bi + 1) / 2;
   bool blk = bi < NBLK;
   int i0 = blk ? 2 * bi : 0, j0 = blk ? 2 * bj : 0;
