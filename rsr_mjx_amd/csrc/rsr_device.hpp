@@ -1773,16 +1773,13 @@ __device__ __forceinline__ float smooth_forces(const DModel& m, const Hot& h, Sm
 struct RowRegs { float aref, D, R, floss, mu; int bn, bk; };
 
 struct Solimp { float v[5]; };
-__device__ __forceinline__ void kbi(const Hot& m, float sr0, float sr1, const Solimp& sip, float pos, float& k, float& b, float& imp) {
+// (stiffness k and damping b of the row come from the lane records: model constants, computed on the host by
+// model.stiffness_damping() exactly as this function computed them per row and substep)
+__device__ __forceinline__ void kbi(const Hot& m, float k_in, float b_in, const Solimp& sip, float pos, float& k, float& b, float& imp) {
   const float* si = sip.v;
-  float timeconst = sr0, dampratio = sr1;
-  if (!m.disable_refsafe) timeconst = fmaxf(timeconst, 2.0f * m.timestep);
   float dmin = clampf(si[0], RSR_MINIMP, RSR_MAXIMP), dmax = clampf(si[1], RSR_MINIMP, RSR_MAXIMP);
   float width = fmaxf(si[2], RSR_MINVAL), mid = clampf(si[3], RSR_MINIMP, RSR_MAXIMP), power = fmaxf(si[4], 1.0f);
-  k = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-  b = 2.0f / (dmax * timeconst);
-  if (sr0 <= 0.0f) k = -sr0 / (dmax * dmax);
-  if (sr1 <= 0.0f) b = -sr1 / dmax;
+  k = k_in; b = b_in;
   float x = fabsf(pos) / width;
   float ia, ib;
   if (power == 2.0f) {       // MuJoCo's default; x*x is the correctly rounded square, as pow(x, 2) is

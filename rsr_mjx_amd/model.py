@@ -148,6 +148,25 @@ def flattened_tables(m: CompiledModel, body_dofmask: np.ndarray) -> Dict[str, np
 LANE_QUADS = 41
 
 
+def stiffness_damping(solref, solimp, timestep, disable_refsafe) -> tuple:
+    """(k, b) of a constraint row's reference acceleration aref = -b v - k imp r, from its solref / solimp: they
+    depend on model constants only, so the host computes them once -- in float32, operation by operation as the kernel did per
+    row and per substep (two to four correctly rounded divisions each) -- and the lane records carry them in place of solref."""
+    f = np.float32
+    sr0, sr1 = f(solref[0]), f(solref[1])
+    timeconst, dampratio = sr0, sr1
+    if not disable_refsafe:
+        timeconst = max(timeconst, f(f(2.0) * f(timestep)))
+    dmax = min(max(f(solimp[1]), f(0.0001)), f(0.9999))
+    k = f(1.0) / f(f(f(f(f(dmax * dmax) * timeconst) * timeconst) * dampratio) * dampratio)
+    b = f(2.0) / f(dmax * timeconst)
+    if sr0 <= 0:
+        k = f(-sr0) / f(dmax * dmax)
+    if sr1 <= 0:
+        b = f(-sr1) / dmax
+    return f(k), f(b)
+
+
 def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=None) -> np.ndarray:
     """Per-lane constant records for the tree stages of the kernel: int32 [LANE_QUADS][64][4] (floats stored by bit pattern).
 
@@ -165,6 +184,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
              19 (i actuator or -1, gear, i qposadr of the joint, i ctrllimited)  20 (ctrl lo, ctrl hi, gainprm0, biasprm0)
              21 (biasprm1, biasprm2, i forcelimited, force lo)  22 (force hi, i actfrclimited, actfrc lo, actfrc hi)
     and, indexed by the constraint-side roles (friction row l, limit slot l, geom pair l, equality l):
+      (every `solref 0 1` below is stored as the row's stiffness / damping (k, b): stiffness_damping())
       fric : 23 (i dof, invweight0, solref 0 1)  24 (solimp 0..3)  25 (solimp 4, 0, 0, 0)
       limit: 26 (i qposadr, i dofadr, range lo hi)  27 (margin, invweight0, solref 0 1)  28 (solimp 0..3)  29 (solimp 4, i joint, 0, 0)
       pair : 30 (i slot of geom1, i slot of geom2, i kind, margin - gap)  31 (size[geom1] xyz, tw)  32 (size[geom2] xyz, i friction rule: 0 max,
@@ -174,6 +194,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
     The joint quad 12 also carries (jnt_axis z, i qposadr, i dofadr, 0) for the integrator.
     """
     A = m.arrays
+    kb = lambda solref, solimp: stiffness_damping(solref, solimp, A["opt_timestep"][0], int(A["opt_disable_refsafe"][0]) != 0)
     rec = np.zeros((LANE_QUADS, 64, 4), dtype=np.int32)
     fv = rec.view(np.float32)
     if max(m.nbody, m.njnt, m.ngeom, m.nsite, m.nv) > 64:
@@ -231,14 +252,14 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
     for l, i in enumerate(topo["fric_dofs"]):
         i = int(i)
         rec[23, l, 0] = i
-        fv[23, l, 1:] = [A["dof_invweight0"][i], *A["dof_solref"][i]]
+        fv[23, l, 1:] = [A["dof_invweight0"][i], *kb(A["dof_solref"][i], A["dof_solimp"][i])]
         fv[24, l] = A["dof_solimp"][i][:4]
         fv[25, l, 0] = A["dof_solimp"][i][4]
     for l, j in enumerate(topo["limit_jnts"]):
         j = int(j)
         rec[26, l, :2] = [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
         fv[26, l, 2:] = A["jnt_range"][j]
-        fv[27, l] = [A["jnt_margin"][j], A["dof_invweight0"][int(A["jnt_dofadr"][j])], *A["jnt_solref"][j]]
+        fv[27, l] = [A["jnt_margin"][j], A["dof_invweight0"][int(A["jnt_dofadr"][j])], *kb(A["jnt_solref"][j], A["jnt_solimp"][j])]
         fv[28, l] = A["jnt_solimp"][j][:4]
         fv[29, l, 0] = A["jnt_solimp"][j][4]
         rec[29, l, 1] = j
@@ -251,7 +272,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
         p1, p2 = int(A["geom_priority"][g1]), int(A["geom_priority"][g2])
         rec[32, q, 3] = 0 if p1 == p2 else (1 if p1 > p2 else 2)
         rec[33, q] = [topo["pair_mask1"][q], topo["pair_mask2"][q], topo["pair_root1"][q], topo["pair_root2"][q]]
-        fv[34, q] = [*A["pair_solref"][q], *A["pair_solimp"][q][:2]]
+        fv[34, q] = [*kb(A["pair_solref"][q], A["pair_solimp"][q]), *A["pair_solimp"][q][:2]]
         fv[35, q, :3] = A["pair_solimp"][q][2:5]
     for e in range(int(A["eq_obj1id"].shape[0])):
         j1, j2 = int(A["eq_obj1id"][e]), int(A["eq_obj2id"][e])
@@ -264,7 +285,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
             rec[37, e, :3] = [1, A["jnt_qposadr"][j2], d2]
         fv[36, e, 3] = invw
         fv[38, e] = A["eq_data"][e][:4]
-        fv[39, e] = [A["eq_data"][e][4], *A["eq_solref"][e], A["eq_solimp"][e][0]]
+        fv[39, e] = [A["eq_data"][e][4], *kb(A["eq_solref"][e], A["eq_solimp"][e]), A["eq_solimp"][e][0]]
         fv[40, e] = A["eq_solimp"][e][1:5]
     return rec
 

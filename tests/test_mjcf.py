@@ -110,6 +110,18 @@ def test_lane_records_restate_the_model_tables(cube_model):
         p1, p2 = A["geom_priority"][g1], A["geom_priority"][g2]
         assert rec[32, q, 3] == (0 if p1 == p2 else (1 if p1 > p2 else 2))
         np.testing.assert_array_equal([*fv[34, q, 2:], *fv[35, q, :3]], f32(A["pair_solimp"][q]))
+    # the rows' stiffness / damping (k, b) stand where solref stood: SURVEY B.10's formulas in double, to float32 rounding
+    dt = float(A["opt_timestep"][0])
+    def kb64(solref, solimp):
+        tc, dr = max(float(solref[0]), 2 * dt), float(solref[1])
+        dmax = min(max(float(solimp[1]), 1e-4), 0.9999)
+        return 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+    for q in range(m.npair):
+        np.testing.assert_allclose(fv[34, q, :2], kb64(A["pair_solref"][q], A["pair_solimp"][q]), rtol=1e-6)
+    for l, j in enumerate(topo["limit_jnts"]):
+        np.testing.assert_allclose(fv[27, l, 2:], kb64(A["jnt_solref"][j], A["jnt_solimp"][j]), rtol=1e-6)
+    for l, i in enumerate(topo["fric_dofs"]):
+        np.testing.assert_allclose(fv[23, l, 2:], kb64(A["dof_solref"][int(i)], A["dof_solimp"][int(i)]), rtol=1e-6)
     # lanes past a role's count are zero, and the device enum names as many quads as the host packs
     assert not rec[0:8, m.nbody:].any() and not rec[30:36, m.npair:].any()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
