@@ -115,7 +115,9 @@ def test_lane_records_restate_the_model_tables(cube_model):
     def kb64(solref, solimp):
         tc, dr = max(float(solref[0]), 2 * dt), float(solref[1])
         dmax = min(max(float(solimp[1]), 1e-4), 0.9999)
-        return 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+        k = 1.0 / (dmax * dmax * tc * tc * dr * dr) if solref[0] > 0 else -float(solref[0]) / (dmax * dmax)      # (direct form: solref <= 0)
+        b = 2.0 / (dmax * tc) if solref[1] > 0 else -float(solref[1]) / dmax
+        return k, b
     for q in range(m.npair):
         np.testing.assert_allclose(fv[34, q, :2], kb64(A["pair_solref"][q], A["pair_solimp"][q]), rtol=1e-6)
     for l, j in enumerate(topo["limit_jnts"]):
