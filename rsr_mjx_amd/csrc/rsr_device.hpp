@@ -157,7 +157,7 @@ struct Dims {
   // instead of carrying it in NV registers from the mass-matrix stage to the integrator (at 128 VGPRs those registers were
   // spilled: every M.v product re-read its row from scratch memory).
   static constexpr bool TTAIL = TTAIL_;
-  static constexpr bool MROW_LDS = TTAIL_;
+  static constexpr bool MROW_LDS = TTAIL_ || (TREE1_ > 0);
   static constexpr int NGA = NGA_;
   static constexpr int CONDIM = CONDIM_;             // all contact pairs of a model share one condim (checked on the host)
   static constexpr int NINFO = NINFO_;               // floats of env info staged in LDS (Go2: 144)
