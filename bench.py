@@ -30,7 +30,7 @@ BYTES_PER_ENV_STEP = 728           # ... without DR
 VALU_PEAK_WAVE_INST_S = 256 * 4 * 2.4e9 / 2.0   # 1024 SIMDs, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md constants)
 
 
-PROFILE_ROUND = "round2"
+PROFILE_ROUND = "round3"
 
 
 def csrc_sha16() -> str:
@@ -95,28 +95,41 @@ def self_launch(args) -> int:
 
 
 def cpu_baseline(blob: bytes, dr, seconds: float = 12.0, nu: int = 5, act_std: float = 1.0):
-    """The CPU oracle (kind "port") timed on all host cores on a bounded sample of the same workload."""
+    """The CPU oracle (kind "port") timed on all host cores on a bounded sample of the same workload.  The sample is sized to
+    the machine -- 64 envs per OpenMP thread, at least 1024 (the oracle hands out chunks of 8 envs dynamically: eight chunks per
+    thread to balance over) -- and timed as three windows of seconds / 3 each; the median is reported and the three rates beside
+    it (1024 envs on 128 threads, one 12 s window, moved by +-40 % between runs: one chunk per thread leaves the slowest chunk
+    of every step in charge)."""
     from oracle import oracle as O
     from rsr_mjx_amd import prng
     O.build()
     orc = O.Oracle(blob)
     threads = orc.max_threads()
-    n = 1024
+    n = max(1024, 64 * threads)
+    if dr is not None:
+        n = min(n, len(next(iter(dr.values()))))
     sub = None if dr is None else {k: np.ascontiguousarray(v[:n]) for k, v in dr.items()}
     st = orc.new_state(n, sub)
     orc.reset(st, prng.split(prng.PRNGKey(123), n), threads)
     rng = np.random.default_rng(1)
     acts = np.clip(rng.normal(size=(8, n, nu)) * act_std, -1, 1).astype(np.float32)
-    for i in range(3):
+    for i in range(2):
         orc.step(st, acts[i], threads)
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < seconds:
-        orc.step(st, acts[k % 8], threads)
-        k += 1
-    dt = time.perf_counter() - t0
-    return dict(value=n * k / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"oracle/rsr_oracle.c (fp32, OpenMP) on {n} envs x {k} steps of the same workload, {dt:.1f} s")
+    rates, k, total = [], 0, 0.0
+    for w in range(3):
+        t0 = time.perf_counter()
+        k0 = k
+        while time.perf_counter() - t0 < seconds / 3.0:
+            orc.step(st, acts[k % 8], threads)
+            k += 1
+        dt = time.perf_counter() - t0
+        total += dt
+        rates.append(n * (k - k0) / dt)
+    med = float(np.median(rates))
+    return dict(value=med, unit="env-steps/s", cores=threads, kind="port",
+                windows=[float(r) for r in rates], spread=float((max(rates) - min(rates)) / med),
+                sample=f"oracle/rsr_oracle.c (fp32, OpenMP, {threads} threads) on {n} envs ({n // threads} per thread) x {k} steps of the same "
+                       f"workload, median of three {seconds / 3.0:.1f}-s windows ({total:.1f} s)")
 
 
 def sub_batched_rate(envdef, keys, dr, n, ep_len, actions, parts, steps, warmup):
@@ -262,12 +275,9 @@ def main():
         torch.cuda.synchronize()
 
     def rollout_metrics():
-        # end-of-rollout metric gather (the path's only collective)
-        metrics[0] = float(args.steps * n)
-        metrics[1] = state.reward.sum()
-        metrics[2] = state.done.sum()
-        metrics[3] = state.info["episode_metrics"]["sum_reward"].mean()
-        return gather_metrics(metrics)
+        # end-of-rollout metric gather (the path's only collective): one reduction launch over the batch's records
+        # (rsr_rollout_metrics: envs, sum of reward, sum of done, mean episode reward so far), then the all_gather
+        return gather_metrics(env.rollout_metrics(metrics))
 
     for i in range(args.warmup):
         env.step(state, actions[i % npool])
@@ -286,7 +296,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    env_steps = float(metrics_all[:, 0].sum().item())
+    env_steps = float(metrics_all[:, 0].sum().item()) * args.steps
+    timeouts = env.handoff_timeouts()         # outside the timed region: the work queue's sticky error word (0 on a healthy run)
 
     if rank == 0:
         bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536}[args.workload]
@@ -321,7 +332,7 @@ def main():
                           + " (one wavefront per env" + ("" if args.workload.startswith("go2") else "; persistent waves draw (env, substep) work units from a ticket queue") + ")",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
                 "mean_newton_iters_last_substep": stats[0], "mean_linesearch_iters_last_substep": stats[1],
-                "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3],
+                "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3], "handoff_timeouts": timeouts,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_S / 1e9, "unit": "GB/s",

@@ -42,7 +42,8 @@ enum {
   RSR_ERR_ARG = -1,       /* bad argument / malformed blob */
   RSR_ERR_UNSUPPORTED = -2, /* model dims or env kind the kernels are not built for */
   RSR_ERR_HIP = -3,       /* HIP runtime error (message has the hipError string) */
-  RSR_ERR_NOMEM = -4
+  RSR_ERR_NOMEM = -4,
+  RSR_ERR_HANDOFF = -5    /* rsr_batch_check: a work-unit hand-off inside a step launch timed out */
 };
 
 typedef struct rsr_dims {
@@ -67,7 +68,8 @@ enum rsr_field {
   RSR_F_FIRST_QPOS, RSR_F_FIRST_QVEL, RSR_F_FIRST_CTRL, RSR_F_FIRST_WARMSTART, RSR_F_FIRST_TIME,
   RSR_F_FIRST_XPOS, RSR_F_FIRST_SITE_XPOS, RSR_F_FIRST_OBS,
   RSR_F_PRIVILEGED_OBS, RSR_F_FIRST_PRIVILEGED_OBS,  /* Go2 obs['privileged_state'], 123 floats (joystick.py:341-366) */
-  RSR_F_STATS,             /* int32[4]: solver iters, line-search iters, active contacts, dropped contacts */
+  RSR_F_STATS,             /* int32[4]: solver iters, line-search iters, active contacts, dropped contacts (-1: a hand-off
+                            * wait of this env timed out in the last step, see rsr_batch_check) */
   RSR_F_COUNT
 };
 
@@ -110,11 +112,28 @@ int rsr_step(rsr_batch* b, const float* action, void* hip_stream);
  * (strides in elements of 4 bytes); shape[0] = num_envs, shape[1] = field width. */
 int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shape[2], int64_t stride[2]);
 
-/* Scheduling knob of rsr_step, results are bit-identical for every value: the launch runs persistent waves that draw
+/* Scheduling knob of rsr_step, results are bit-identical for every value and for any sequence of values between steps
+ * (tests/test_parity_gpu.py::test_schedule_changes_are_bit_identical): the launch runs persistent waves that draw
  * (env, phase) work units from a queue, an env-step being cut into `units` groups of consecutive physics substeps
- * (1 <= units <= n_frames; larger values are clamped).  Shorter units shorten the drain at the end of a launch.  No
- * counterpart in the reference (XLA schedules its own kernels).  The Go2 kernels ignore it for now. */
+ * (1 <= units <= min(n_frames, 64); larger values are clamped).  Shorter units shorten the drain at the end of a launch.
+ * No counterpart in the reference (XLA schedules its own kernels).  The Go2 kernels ignore it. */
 int rsr_batch_set_schedule(rsr_batch* b, int units);
+
+/* Health of the work queue.  A phase of an env waits for the previous phase's hand-off with a bounded spin; a wait that
+ * times out is counted on the device (sticky for the batch's lifetime), the env's later phases inherit the mark, and the
+ * env's stats[3] reads -1 after that step.  rsr_batch_check synchronises `hip_stream`, copies the count to
+ * *handoff_timeouts (may be NULL) and returns RSR_ERR_HANDOFF if it is not zero.  No counterpart in the reference. */
+int rsr_batch_check(rsr_batch* b, void* hip_stream, int* handoff_timeouts);
+
+/* Test hook for the above: `spin_cap` polls before a wait gives up (<= 0: the default, about a second), and phase 0 of env
+ * `withhold_env` never publishes its hand-off flag (-1: none), so that env's next phase times out. */
+int rsr_batch_set_fault_injection(rsr_batch* b, int spin_cap, int withhold_env);
+
+/* End-of-rollout metric reduction (the reduction in front of the path's one collective: the reference's training loops average
+ * the episode metrics of a rollout over the env batch, RSR/train.py:441-447 via acting.Evaluator): one launch writes
+ * dev_out[4] = { num_envs, sum of reward, sum of done, mean over envs of the running episode's summed reward }, summed in a
+ * fixed order.  dev_out: device float[4]. */
+int rsr_rollout_metrics(rsr_batch* b, float* dev_out, void* hip_stream);
 
 /* Optional per-stage dump for parity debugging: device float buffer [num_envs, RSR_DEBUG_FLOATS]
  * filled by the next rsr_step/rsr_reset from the LAST physics forward pass (NULL disables). */

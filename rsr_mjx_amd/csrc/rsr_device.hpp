@@ -119,10 +119,19 @@ struct Layout {
 // already idle (8192 envs = 4 rounds of 2048 slots: ~20 % of the launch); shorter units shorten that drain.
 struct Sched {
   int* ticket;          // [2]: counter of launch `launch_id & 1`; the wave that draws ticket 0 zeroes the other one
-  unsigned* flags;      // [n]: launch_id * units + (phases of the env completed in this launch)
+  int* err;             // [2]: hand-off waits that timed out since the batch was created (sticky), and the env of the last one
+  unsigned* flags;      // [n]: (launch_id << 8) | phases of the env completed in this launch | RSR_FLAG_ERR
   unsigned launch_id;   // 1, 2, ... per rsr_step of the batch
-  int units;            // phases per env-step (1 = the whole step in one unit)
+  int units;            // phases per env-step (1 = the whole step in one unit), at most RSR_MAX_UNITS
+  int spin_cap;         // bound of the hand-off poll (sleeps of 8 x 64 cycles); test hook: rsr_batch_set_fault_injection
+  int withhold_env;     // test hook: phase 0 of this env never publishes its flag (-1: none)
 };
+// The flag word does not depend on `units` (a stale flag of an earlier launch can never equal a later launch's value, whatever
+// rsr_batch_set_schedule did in between), and carries an error bit down the phases of an env: a phase whose wait timed out
+// runs on whatever the record holds, publishes with the bit set, and the env's last phase reports stats[3] = -1.
+#define RSR_FLAG_ERR 0x80u
+#define RSR_MAX_UNITS 64
+#define RSR_SPIN_CAP_DEFAULT (1 << 22)
 
 // relaxed agent-scope accesses = global_load / global_store ... sc1: served by / written through to memory, past the CU's L1
 // and the XCD's L2, which are not coherent across CUs / XCDs within a launch (MI355X_MICROARCH.md, inter-workgroup visibility)

@@ -491,17 +491,26 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   PROF_DECL
   // ---- load the record ----
   float warm = 0.0f, time;
+  unsigned handoff_err = 0u;
   if (first) {
     for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
     if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
     time = rec[L.time];
   } else {
     // the previous phase of this env (another wave, any CU) has published its state: poll its flag, then read every handed-off
-    // word past the caches.  The spin is bounded; a timeout is reported through stats[3] = -1 and the unit runs on stale data.
-    const unsigned want = sc.launch_id * (unsigned)units + (unsigned)phase;
+    // word past the caches.  The spin is bounded; a timeout is sticky: counted in sc.err, carried to the env's later phases in
+    // the flag's error bit, and reported by the last phase as stats[3] = -1 (the unit runs on whatever the record holds).
+    const unsigned want = (sc.launch_id << 8) | (unsigned)phase;
     int spins = 0;
-    while (__hip_atomic_load(sc.flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(8); ++spins; }
-    if (spins >= (1 << 22) && lane == 0) reinterpret_cast<int*>(rec + L.stats)[3] = -1;
+    unsigned fl;
+    while (((fl = __hip_atomic_load(sc.flags + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~RSR_FLAG_ERR) != want && spins < sc.spin_cap) { __builtin_amdgcn_s_sleep(8); ++spins; }
+    fl = (unsigned)uniform_i((int)fl);
+    const bool timed_out = (fl & ~RSR_FLAG_ERR) != want;
+    handoff_err = timed_out ? RSR_FLAG_ERR : (fl & RSR_FLAG_ERR);
+    if (timed_out && lane == 0) {
+      __hip_atomic_fetch_add(sc.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sc.err + 1, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = ld_sc1(&rec[L.qpos + t]);
     if (lane < C::NV) { s.qvel[lane] = ld_sc1(&rec[L.qvel + lane]); warm = ld_sc1(&rec[L.warm + lane]); }
     if (lane < C::NU) s.ctrl[lane] = ld_sc1(&rec[L.ctrl + lane]);
@@ -572,7 +581,8 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
     if (lane < C::NU) st_sc1(&rec[L.ctrl + lane], s.ctrl[lane]);
     if (lane == 0) st_sc1(&rec[L.time], time);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(sc.flags + e, sc.launch_id * (unsigned)units + (unsigned)phase + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && !(first && e == sc.withhold_env))
+      __hip_atomic_store(sc.flags + e, (sc.launch_id << 8) | (unsigned)(phase + 1) | handoff_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300 + 8 * phase, prof_rt0_, prof_ct0_);
 #endif
@@ -680,7 +690,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
     rec[L.steps] = steps;
     rec[L.done] = done;
     int* st = reinterpret_cast<int*>(rec + L.stats);
-    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = handoff_err ? -1 : s.ncon_drop;
   }
   WSYNC();
   done = rdlane(done, 0);
@@ -1186,6 +1196,29 @@ void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs
 }
 #endif
 
+#ifndef RSR_TU_GO2
+// ---------------------------------------------------------------- end-of-rollout metric reduction
+// One launch instead of a handful of library reductions: out = {envs, sum of reward, sum of done, mean of the running episode's
+// summed reward} over the batch, summed in a fixed order (per-thread strided partial sums, then a binary tree in LDS), so the
+// result does not depend on timing.  One workgroup: the batch is a few thousand records and the launch is latency bound.
+__global__ __launch_bounds__(1024) void rollout_metrics_kernel(const float* __restrict__ state, Layout L, int n, float* __restrict__ out) {
+  __shared__ float red[3][1024];
+  const int t = threadIdx.x;
+  float r = 0.0f, d = 0.0f, em = 0.0f;
+  for (int e = t; e < n; e += 1024) {
+    const float* rec = state + (size_t)e * L.rec;
+    r += rec[L.reward]; d += rec[L.done]; em += rec[L.episode_metrics];
+  }
+  red[0][t] = r; red[1][t] = d; red[2][t] = em;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; red[2][t] += red[2][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) { out[0] = (float)n; out[1] = red[0][0]; out[2] = red[1][0]; out[3] = red[2][0] / (float)n; }
+}
+#endif
+
 }  // namespace rsr
 
 #ifndef RSR_TU_GO2
@@ -1231,9 +1264,10 @@ struct rsr_batch {
   float* debug;
   hipEvent_t ev0, ev1; bool timing; int launches;
   // work-queue dispatch of the Airbot step kernels (rsr_device.hpp: Sched)
-  int* sched;           // device: ticket[2], then flags[n]
+  int* sched;           // device: ticket[2], err[2], then flags[n]
   unsigned launch_id;
   int units, step_grid;
+  int spin_cap, withhold_env;   // rsr_batch_set_fault_injection (test hook)
 };
 
 static Layout make_layout(const rsr_dims& d) {
@@ -1500,9 +1534,9 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     if (ce != hipSuccess) { release(); return fail(RSR_ERR_HIP, std::string("rsr_batch_create: hipMemcpy(model): ") + hipGetErrorString(ce)); } }
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { release(); return rc; }
-  b->launch_id = 0; b->units = 1; b->step_grid = 0;
+  b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1;
   if (m->dims.env_kind != rsr::ENV_GO2) {
-    const size_t sb = (2 + (size_t)num_envs) * sizeof(int);
+    const size_t sb = (4 + (size_t)num_envs) * sizeof(int);
     if (hipMalloc(&b->sched, sb) != hipSuccess) { b->sched = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
     (void)hipMemset(b->sched, 0, sb);
     // resident waves of the step kernel on this device: the grid of the persistent launch
@@ -1516,6 +1550,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     b->units = ev ? std::atoi(ev) : RSR_DEFAULT_UNITS;
     if (b->units < 1) b->units = 1;
     if (b->units > m->dims.n_frames) b->units = m->dims.n_frames;
+    if (b->units > RSR_MAX_UNITS) b->units = RSR_MAX_UNITS;
   }
   if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { b->dmodel = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
   { hipError_t ce = hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice);
@@ -1562,6 +1597,27 @@ extern "C" int rsr_batch_set_dr_field(rsr_batch* b, int dr_field, const float* d
 extern "C" int rsr_batch_set_schedule(rsr_batch* b, int units) {
   if (!b || units < 1) return fail(RSR_ERR_ARG, "rsr_batch_set_schedule: bad argument");
   b->units = units > b->model->dims.n_frames ? b->model->dims.n_frames : units;
+  if (b->units > RSR_MAX_UNITS) b->units = RSR_MAX_UNITS;
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_set_fault_injection(rsr_batch* b, int spin_cap, int withhold_env) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_fault_injection: null batch");
+  b->spin_cap = spin_cap > 0 ? spin_cap : RSR_SPIN_CAP_DEFAULT;
+  b->withhold_env = (withhold_env >= 0 && withhold_env < b->n) ? withhold_env : -1;
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_check(rsr_batch* b, void* hip_stream, int* handoff_timeouts) {
+  if (!b) return fail(RSR_ERR_ARG, "rsr_batch_check: null batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+  int err[2] = {0, 0};
+  if (b->sched) HIPCHK(hipMemcpy(err, b->sched + 2, sizeof(err), hipMemcpyDeviceToHost));
+  if (handoff_timeouts) *handoff_timeouts = err[0];
+  if (err[0] > 0)
+    return fail(RSR_ERR_HANDOFF, "rsr_batch_check: " + std::to_string(err[0]) + " work-unit hand-off wait(s) timed out since the batch was created (last: env " +
+                                     std::to_string(err[1]) + "); those envs' stats[3] read -1 for the step concerned and their state is not to be trusted");
   return RSR_OK;
 }
 
@@ -1607,7 +1663,12 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   if (b->model->dims.env_kind == rsr::ENV_GO2)
     rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a);
   else {
-    rsr::Sched sc{b->sched, reinterpret_cast<unsigned*>(b->sched + 2), ++b->launch_id, b->units};
+    ++b->launch_id;
+    if ((b->launch_id & 0xFFFFFFu) == 0u) {        // the flags carry 24 bits of the launch number: clear them before the number repeats
+      ++b->launch_id;
+      HIPCHK(hipMemsetAsync(b->sched + 4, 0, (size_t)b->n * sizeof(int), st));
+    }
+    rsr::Sched sc{b->sched, b->sched + 2, reinterpret_cast<unsigned*>(b->sched + 4), b->launch_id, b->units, b->spin_cap, b->withhold_env};
     const long long work = (long long)b->units * b->n;
     const int grid = (int)(RSR_PERSISTENT && work > b->step_grid ? b->step_grid : work);
     if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
@@ -1671,6 +1732,14 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
   *dev_ptr = b->state + off;
   shape[0] = b->n; shape[1] = w;
   stride[0] = L.rec; stride[1] = 1;
+  return RSR_OK;
+}
+
+extern "C" int rsr_rollout_metrics(rsr_batch* b, float* dev_out, void* hip_stream) {
+  if (!b || !dev_out) return fail(RSR_ERR_ARG, "rsr_rollout_metrics: null argument");
+  HIPCHK(hipSetDevice(b->device));
+  hipLaunchKernelGGL(rsr::rollout_metrics_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(hip_stream), b->state, b->model->layout, b->n, dev_out);
+  HIPCHK(hipGetLastError());
   return RSR_OK;
 }
 

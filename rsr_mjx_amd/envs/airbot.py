@@ -235,6 +235,32 @@ class BatchedEnv:
         """Work units per env-step of the persistent step launch (results are bit-identical for every value)."""
         _lib.check(_lib.lib().rsr_batch_set_schedule(self._batch, int(units)))
 
+    def rollout_metrics(self, out=None):
+        """One launch: float tensor [4] = (num_envs, sum of reward, sum of done, mean of the running episodes' summed reward) of
+        this batch (rsr_rollout_metrics); needs the Episode wrapper's bookkeeping for the last entry."""
+        import torch
+        if out is None:
+            out = torch.empty(4, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().rsr_rollout_metrics(self._batch, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def handoff_timeouts(self) -> int:
+        """Synchronises the launch stream and returns the number of work-unit hand-off waits that timed out since the batch was
+        created (rsr_batch_check; 0 on a healthy batch).  The envs concerned read stats[:, 3] == -1 after that step."""
+        n = C.c_int()
+        rc = _lib.lib().rsr_batch_check(self._batch, self._stream(), C.byref(n))
+        if rc not in (0, -5):
+            _lib.check(rc)
+        return int(n.value)
+
+    def check(self) -> None:
+        """Raises if any hand-off wait has timed out (rsr_batch_check)."""
+        _lib.check(_lib.lib().rsr_batch_check(self._batch, self._stream(), None))
+
+    def set_fault_injection(self, spin_cap: int = 0, withhold_env: int = -1) -> None:
+        """Test hook (rsr_batch_set_fault_injection)."""
+        _lib.check(_lib.lib().rsr_batch_set_fault_injection(self._batch, int(spin_cap), int(withhold_env)))
+
     def enable_debug(self, on: bool = True):
         import torch
         if on:

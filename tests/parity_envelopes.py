@@ -3,9 +3,13 @@
 The envelopes derive from what was measured on an MI355X over 2048 envs x 3 rollout depths per workload
 (tools/gpu_parity_stats.py -> tools/make_parity_envelopes.py; the JSON keeps the measured values and the hash of the kernel
 sources they were measured on).  err = |hip - oracle| / max(1, |oracle|_inf of that env's field), per env.  For every
-(workload, phase, field), with max = max(1e-5, 5 x the measured maximum):   99.9 % of the envs within max (samples of
->= 1000 envs), none beyond 30 x max,   quantile(err, 0.99) <= p99 (samples of >= 1000 envs),   and at most 1 % of the envs above
-1e-5 where the measurement found none (obs, reward, xpos ... on the Airbot envs).
+(workload, phase, field), with max = max(1e-5, 5 x the measured maximum):
+  samples of >= 1000 envs:  99.9 % of the envs within max, none beyond 30 x max, quantile(err, 0.99) <= p99;
+  smaller samples:          at most ONE env above max and none beyond 5 x max (the 4-env goldens, the 64-env wrapper tests:
+                            a small sample has no quantiles to speak of, so it is held to the bound itself);
+  and at most 1 % of the envs above 1e-5 where the measurement found none (obs, reward, xpos ... on the Airbot envs).
+The JSON's _provenance.csrc_sha16 is the hash of the kernel sources the envelopes were measured on;
+test_parity_gpu.py::test_envelopes_were_measured_on_these_kernel_sources fails when it is not the hash of the sources in the tree.
 Phases: "reset" = the env-step straight after reset, "rollout" = any later step.
 
 What the numbers say (north_star: 1e-5 relative fp32):
@@ -52,10 +56,14 @@ def check(kind, phase, field, got, want, tag="", quantiles=True):
         return err
     e = ENV[kind][phase][field]
     # the tail is heavy (ill-conditioned solves, contact-mode switches: one env in ~3000 env-steps lands 20-30 x beyond the
-    # measured maximum of a 6000-sample run): one env in a thousand may pass the bound, none may pass 30 x it
-    assert err.max() <= 30.0 * e["max"], (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)))
+    # measured maximum of a 6000-sample run): in a large sample one env in a thousand may pass the bound, none may pass 30 x it;
+    # a small sample is held to the bound itself -- one env may pass it, by less than 5 x
     if len(err) >= 1000:
+        assert err.max() <= 30.0 * e["max"], (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)))
         assert np.quantile(err, 0.999) <= e["max"], (tag, kind, phase, field, "p99.9", float(np.quantile(err, 0.999)), e["max"])
+    else:
+        assert int((err > e["max"]).sum()) <= 1, (tag, kind, phase, field, "envs above max in a small sample", np.nonzero(err > e["max"])[0].tolist(), e["max"])
+        assert err.max() <= 5.0 * e["max"], (tag, kind, phase, field, "max (small sample)", float(err.max()), 5.0 * e["max"], int(np.argmax(err)))
     if quantiles and len(err) >= 1000:
         assert np.quantile(err, 0.99) <= e["p99"], (tag, kind, phase, field, "p99", float(np.quantile(err, 0.99)), e["p99"])
     if quantiles and len(err) >= 200 and e["measured"]["frac"] <= 0.002:

