@@ -91,3 +91,38 @@ def ppo_loss(logits, baseline, bootstrap, reward, discount, truncation, raw_acti
     v_loss = np.mean((vs - baseline) ** 2) * 0.5 * 0.5
     entropy_loss = entropy_cost * -np.mean(entropy(logits, noise))
     return policy_loss + v_loss + entropy_loss + rsr_term, policy_loss, v_loss, entropy_loss
+
+
+# ---- SAC (RSR/sac_losses.py:23-130, after brax 0.12.1 agents/sac/losses.py) ----
+# The networks enter as plain callables on numpy arrays (policy(obs) -> logits, q(obs, action) -> [..., 2], the twin critics);
+# `noise` is the standard-normal draw the reference takes from `key` (sample_no_postprocessing = loc + scale * eps).
+def sac_sample(logits, noise):
+    loc, scale = tanh_normal(logits)
+    return loc + scale * noise
+
+
+def sac_alpha_loss(log_alpha, policy, obs, noise, action_size):                                          # :40-55
+    logits = policy(obs)
+    lp = log_prob(logits, sac_sample(logits, noise))
+    return np.mean(np.exp(log_alpha) * (-lp - (-0.5 * action_size)))      # target_entropy = -0.5 * action_size (:33)
+
+
+def sac_critic_loss(q, target_q, policy, alpha, obs, action, reward, discount, next_obs, truncation, noise,
+                    reward_scaling, discounting):                                                     # :57-98
+    old_q = q(obs, action)
+    nlogits = policy(next_obs)
+    nraw = sac_sample(nlogits, noise)
+    next_q = target_q(next_obs, np.tanh(nraw))
+    next_value = next_q.min(axis=-1) - alpha * log_prob(nlogits, nraw)
+    target = reward * reward_scaling + discount * discounting * next_value
+    q_error = (old_q - target[..., None]) * (1 - truncation)[..., None]
+    return 0.5 * np.mean(q_error ** 2)
+
+
+def sac_actor_loss(q, policy, alpha, obs, next_obs, noise, rsr_fn=None):                                  # :100-128
+    """rsr_fn(obs, action, next_obs) -> the RSR penalty (compute_rsr_loss above with the reference data bound); None = 0."""
+    logits = policy(obs)
+    raw = sac_sample(logits, noise)
+    action = np.tanh(raw)
+    base = np.mean(alpha * log_prob(logits, raw) - q(obs, action).min(axis=-1))
+    return base + (rsr_fn(obs, action, next_obs) if rsr_fn is not None else 0.0), base

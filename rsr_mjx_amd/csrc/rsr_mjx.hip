@@ -1545,6 +1545,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>, 64, sizeof(rsr::Smem<rsr::TShapeDims>))
       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>, 64, sizeof(rsr::Smem<rsr::CubeDims>));
     if (oe != hipSuccess || hipGetDeviceProperties(&prop, hip_device) != hipSuccess || per_cu <= 0) { per_cu = 8; prop.multiProcessorCount = 256; }
+    if (const char* gv = std::getenv("RSR_GRID_PER_CU")) { const int g = std::atoi(gv); if (g > 0 && g < per_cu) per_cu = g; }   // diagnostic: fewer resident waves
     b->step_grid = per_cu * prop.multiProcessorCount;
     const char* ev = std::getenv("RSR_UNITS");
     b->units = ev ? std::atoi(ev) : RSR_DEFAULT_UNITS;

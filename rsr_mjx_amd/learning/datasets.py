@@ -26,7 +26,7 @@ def load_table(path) -> np.ndarray:
     with open(path) as f:
         rows = [ln for ln in f if ln.strip()]
     if not rows:
-        raise ValueError(f"{path.name} is empty.")
+        raise ValueError(f"{path.name}: no rows of numbers in this file")
     table = np.loadtxt(rows, delimiter=",", ndmin=2)
     return table
 
@@ -37,30 +37,29 @@ def load_rsr_datasets(data_dir, max_transitions: int = 50, verbose: bool = False
     data_dir = Path(data_dir)
     missing = [name for name in REQUIRED_DATA_FILES if not (data_dir / name).is_file()]
     if missing:
-        raise FileNotFoundError(f"Required dataset file not found: {data_dir / missing[0]}. Expected files: {', '.join(REQUIRED_DATA_FILES)}")
+        raise FileNotFoundError(f"{data_dir}: missing {', '.join(missing)} (an RSR data directory holds {', '.join(REQUIRED_DATA_FILES)})")
     tables: Dict[str, np.ndarray] = {name: load_table(data_dir / name) for name in REQUIRED_DATA_FILES}
 
     real_obs, real_action = tables["real_obs.txt"], tables["real_action.txt"]
     count = min(len(real_obs) - 1, len(real_action), int(max_transitions))
     if count <= 0:
-        raise ValueError("Not enough aligned transitions in real_obs.txt and real_action.txt. Need at least 2 observations and 1 action.")
+        raise ValueError(f"real_obs.txt ({len(real_obs)} rows) and real_action.txt ({len(real_action)} rows) give no transition: "
+                         "a transition takes two consecutive observations and the action between them")
     obs_dim, action_dim = real_obs.shape[1], real_action.shape[1]
 
     for name in _OBS_TABLES[1:]:
         if len(tables[name]) < count + 1:
-            raise ValueError(f"{name} needs at least {count + 1} rows for {count} transitions, found {len(tables[name])}.")
+            raise ValueError(f"{name}: {len(tables[name])} rows, but {count} transitions take {count + 1} observations")
     if len(tables["actions.txt"]) < count:
-        raise ValueError(f"actions.txt needs at least {count} rows, found {len(tables['actions.txt'])}.")
+        raise ValueError(f"actions.txt: {len(tables['actions.txt'])} rows, but {count} transitions take {count} actions")
     for names, width, label in ((_OBS_TABLES, obs_dim, "observation"), (_ACTION_TABLES, action_dim, "action")):
         for name in names:
             if tables[name].shape[1] != width:
-                raise ValueError(f"{name} must have {width} {label} features, found shape {tables[name].shape}.")
+                raise ValueError(f"{name}: {tables[name].shape[1]} columns where the real data's {label}s have {width}")
 
     if verbose:
-        print("====== RSR dataset summary ======")
-        print(f"data_dir: {data_dir}")
-        print(f"transitions: {count}")
+        print(f"RSR data from {data_dir}: {count} transitions, {obs_dim}-dim observations, {action_dim}-dim actions")
         for name in REQUIRED_DATA_FILES:
-            print(f"{name}: {data_dir / name}")
+            print(f"  {name}: {tables[name].shape[0]} x {tables[name].shape[1]}")
     return (real_obs[:count], real_action[:count], real_obs[1:count + 1],
             tables["past_sim_obs.txt"][1:count + 1], tables["current_sim_obs.txt"][1:count + 1])

@@ -481,7 +481,7 @@ def test_go2_truncation_and_autoreset_on_device(oracle_mod):
                 # the other side of a step boundary; at most one env in 200 may differ by more than 0.05)
                 assert k in ("qvel", "qacc_warmstart") or np.mean(e[~done] > 0.05) <= 0.005, (t, k, float(e[~done].max()), float(np.mean(e[~done] > 0.05)))
         em = serr(get("info_episode_metrics"), st["info_episode_metrics"])      # sums of reward terms: same touch-down tail as the physics
-        assert np.quantile(em, 0.99) <= 1e-4 and em.max() <= 0.05, (t, float(np.quantile(em, 0.99)), float(em.max()))
+        assert np.quantile(em, 0.99) <= 1e-4 and np.mean(em > 0.05) <= 0.005, (t, float(np.quantile(em, 0.99)), float(em.max()))
         if done.any():
             # AutoReset: the cached first state replaces pipeline state and observations, bit for bit
             np.testing.assert_array_equal(get("obs")[done], first_obs[done])

@@ -433,6 +433,63 @@ def test_device_losses_match_the_numpy_restatement():
     assert R.kl_divergence(c(p), c(q)).item() == pytest.approx(O.kl_divergence(p, q), rel=1e-4)
 
 
+def _sac_losses_case(dev):
+    """f2, SAC leg: alpha, critic (with the truncation mask) and actor + RSR losses AS THEY RUN ON THE GPU (fp32 on cuda:0)
+    against the independent numpy fp64 restatement of RSR/sac_losses.py:40-128 (oracle/losses_np.py: sac_*), same weights,
+    same noise draws.  Networks: a linear policy and twin critics with a tanh layer, written once per side."""
+    rng = np.random.default_rng(29)
+    B, Do, A = 96, 23, 5
+    obs, nobs = rng.normal(size=(B, Do)), rng.normal(size=(B, Do))
+    act = np.tanh(rng.normal(size=(B, A)))
+    reward, discount = rng.normal(size=B), (rng.uniform(size=B) > 0.1).astype(np.float64)
+    trunc = (rng.uniform(size=B) > 0.8).astype(np.float64)
+    Wp = rng.normal(size=(Do, 2 * A)) * 0.3
+    Wq1, Wq2, Wt1, Wt2 = (rng.normal(size=(Do + A, 16)) * 0.3 for _ in range(4))
+    vq1, vq2, vt1, vt2 = (rng.normal(size=16) * 0.5 for _ in range(4))
+    n_alpha, n_critic, n_actor = rng.normal(size=(B, A)), rng.normal(size=(B, A)), rng.normal(size=(B, A))
+    log_alpha, rs, disc = -0.7, 2.0, 0.97
+    # numpy side
+    pol = lambda o: o @ Wp
+    twin = lambda W1, v1, W2, v2: (lambda o, a: np.stack([np.tanh(np.concatenate([o, a], -1) @ W1) @ v1, np.tanh(np.concatenate([o, a], -1) @ W2) @ v2], -1))
+    q_np, tq_np = twin(Wq1, vq1, Wq2, vq2), twin(Wt1, vt1, Wt2, vt2)
+    ref = rng.normal(size=(150, Do + A + Do))
+    # torch side
+    c = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    rd = R.build_rsr_data(c(ref), c(ref * 1.1 + 0.05), c(ref * 0.95), num_samples=10, bandwidth=3.0)
+    wp = c(Wp)
+    ttwin = lambda W1, v1, W2, v2: (lambda o, a: torch.stack([torch.tanh(torch.cat([o, a], -1) @ c(W1)) @ c(v1), torch.tanh(torch.cat([o, a], -1) @ c(W2)) @ c(v2)], -1))
+    q_t, tq_t = ttwin(Wq1, vq1, Wq2, vq2), ttwin(Wt1, vt1, Wt2, vt2)
+    tr = Transition(c(obs), c(act), c(reward), c(discount), c(nobs), {"state_extras": {"truncation": c(trunc)}})
+    alpha_loss, critic_loss, actor_loss = S.make_losses(lambda o: o @ wp, q_t, rs, disc, A, past_data=rd, rsr_loss_scale=1.5)
+    la = torch.tensor(log_alpha, device=dev)
+    alpha = float(np.exp(log_alpha))
+    got_alpha = alpha_loss(la, tr, c(n_alpha)).item()
+    got_critic = critic_loss(q_t, tq_t, alpha, tr, c(n_critic)).item()
+    got_actor = actor_loss(q_t, alpha, tr, c(n_actor)).item()
+    # restatement
+    want_alpha = O.sac_alpha_loss(log_alpha, pol, obs, n_alpha, A)
+    want_critic = O.sac_critic_loss(q_np, tq_np, pol, alpha, obs, act, reward, discount, nobs, trunc, n_critic, rs, disc)
+    grid = rd.grid.double().cpu().numpy()
+    dens_real, dens_prev, dens_cur = (O.evaluate_kde(v, grid, 3.0) for v in (ref, ref * 1.1 + 0.05, ref * 0.95))
+    kl = O.kl_divergence(dens_real, dens_prev)
+    rsr_fn = lambda o, a, no: O.compute_rsr_loss(o, a, no, kl, dens_cur, ref * 0.95, grid, 3.0, loss_scale=1.5)[0]
+    want_actor, want_base = O.sac_actor_loss(q_np, pol, alpha, obs, nobs, n_actor, rsr_fn)
+    assert got_alpha == pytest.approx(want_alpha, rel=2e-4, abs=1e-6)
+    assert got_critic == pytest.approx(want_critic, rel=5e-4)
+    assert got_actor == pytest.approx(want_actor, rel=2e-3, abs=2e-5) and abs(want_actor - want_base) > 1e-4      # the RSR term is in there
+    # the truncation mask matters: without it the critic loss is a different number
+    assert abs(O.sac_critic_loss(q_np, tq_np, pol, alpha, obs, act, reward, discount, nobs, np.zeros(B), n_critic, rs, disc) - want_critic) > 1e-3 * abs(want_critic)
+
+
+def test_sac_losses_match_the_numpy_restatement_on_the_host():
+    _sac_losses_case(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_device_sac_losses_match_the_numpy_restatement():
+    _sac_losses_case(torch.device("cuda:0"))
+
+
 def test_sac_sgd_step_uses_the_entering_training_state():
     """brax 0.12.1 sac/train.py sgd_step: alpha, critic and actor losses are all evaluated at the training state as it entered
     the step (alpha before the alpha update, the actor against the critic before the critic update); the target critic then
@@ -548,14 +605,14 @@ def test_rsr_dataset_tables(tmp_path):
     with pytest.raises(FileNotFoundError, match="obs.txt"):
         D.load_rsr_datasets(d)
     short = dict(tabs); short["current_sim_obs.txt"] = tabs["current_sim_obs.txt"][:T]
-    with pytest.raises(ValueError, match="current_sim_obs.txt needs at least 13 rows"):
+    with pytest.raises(ValueError, match="current_sim_obs.txt: 12 rows, but 12 transitions take 13 observations"):
         D.load_rsr_datasets(write(tmp_path / "b", short))
     wide = dict(tabs); wide["actions.txt"] = rng.normal(size=(T, ad + 1))
-    with pytest.raises(ValueError, match="actions.txt must have 2 action features"):
+    with pytest.raises(ValueError, match="actions.txt: 3 columns where the real data's actions have 2"):
         D.load_rsr_datasets(write(tmp_path / "c", wide))
     few = dict(tabs); few["real_obs.txt"] = tabs["real_obs.txt"][:1]
-    with pytest.raises(ValueError, match="Not enough aligned transitions"):
+    with pytest.raises(ValueError, match="give no transition"):
         D.load_rsr_datasets(write(tmp_path / "e", few))
     e = write(tmp_path / "f", tabs); (e / "real_obs.txt").write_text("")
-    with pytest.raises(ValueError, match="real_obs.txt is empty"):
+    with pytest.raises(ValueError, match="real_obs.txt: no rows of numbers"):
         D.load_rsr_datasets(e)

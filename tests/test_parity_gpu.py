@@ -556,7 +556,7 @@ def test_handoff_timeout_is_sticky_and_visible():
     """The work queue's error path, exercised once: with the poll bound cut to about two milliseconds (far above a unit's ~50 us,
     so no healthy wait gives up: all 4 x 512 units of this batch are resident at once and every phase 1 waits a whole unit) and
     phase 0 of one env never publishing its flag, that env's phase 1 gives up.  The host must be able to see it -- stats[env, 3] == -1 after the step
-    (the later phases inherit the mark; the last phase does not overwrite it), rsr_batch_check counts exactly one timeout and
+    (the later phases inherit the mark; the last phase does not overwrite it), rsr_batch_check counts the timeouts and
     fails -- and every other env must be bit-identical to a clean batch's."""
     import torch
     from rsr_mjx_amd import prng
@@ -572,7 +572,9 @@ def test_handoff_timeout_is_sticky_and_visible():
     assert st[victim, 3] == -1, st[victim]
     others = np.arange(n) != victim
     assert (st[others, 3] >= 0).all()
-    assert hurt.handoff_timeouts() == 1 and clean.handoff_timeouts() == 0
+    # (the env's later phases are resident too in so small a batch and started polling at the same moment: they give up as well)
+    nt = hurt.handoff_timeouts()
+    assert 1 <= nt <= 3 and clean.handoff_timeouts() == 0, nt
     with pytest.raises(RuntimeError, match="hand-off"):
         hurt.check()
     ra, rb = clean.record.view(torch.int32).cpu().numpy(), hurt.record.view(torch.int32).cpu().numpy()
@@ -580,7 +582,7 @@ def test_handoff_timeout_is_sticky_and_visible():
     # the mark is per step: with the hook off the env steps cleanly again, the batch's count stays (sticky)
     hurt.set_fault_injection()
     hurt.step(None, act)
-    assert int(hurt.view("stats")[victim, 3]) >= 0 and hurt.handoff_timeouts() == 1
+    assert int(hurt.view("stats")[victim, 3]) >= 0 and hurt.handoff_timeouts() == nt
 
 
 def test_envelopes_were_measured_on_these_kernel_sources():
