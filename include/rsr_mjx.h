@@ -119,6 +119,13 @@ int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shape[2], int64
  * No counterpart in the reference (XLA schedules its own kernels).  The Go2 kernels ignore it. */
 int rsr_batch_set_schedule(rsr_batch* b, int units);
 
+/* Second scheduling knob, results bit-identical for every value as well: the first `whole_envs` envs of the batch are stepped as
+ * ONE work unit each whatever `units` says (no hand-off through memory, one ticket), only the rest is cut into `units` phases.
+ * Long units first, short units last: the launch still drains in short units while most envs skip the per-unit overhead.
+ * -1 (the default): all but twice as many envs as there are resident waves (a phase of a split env then finds the previous
+ * one finished two rounds ago instead of waiting for it); 0: every env is split (the behaviour before round 3). */
+int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs);
+
 /* Health of the work queue.  A phase of an env waits for the previous phase's hand-off with a bounded spin; a wait that
  * times out is counted on the device (sticky for the batch's lifetime), the env's later phases inherit the mark, and the
  * env's stats[3] reads -1 after that step.  rsr_batch_check synchronises `hip_stream`, copies the count to

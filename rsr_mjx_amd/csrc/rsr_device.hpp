@@ -112,17 +112,20 @@ struct Layout {
 };
 
 // Work-queue dispatch of a step launch (persistent waves).  An env-step is cut into `units` consecutive groups of physics
-// substeps; a wave draws tickets t = phase * n + env from one counter and runs unit `phase` of `env`, handing the pipeline
+// substeps (the first n_whole envs: into one); a wave draws tickets from one counter -- the whole envs first, then
+// t = phase * n_split + env over the split ones -- and runs unit `phase` of `env`, handing the pipeline
 // state (qpos, qvel, ctrl, qacc_warmstart, time) to the next phase through the env's record.  Tickets are drawn in
 // dependency order, so the wave that holds (env, phase - 1) drew its ticket earlier and is running: waits always end.
 // Why: with one launch-long unit per env the last waves of a launch run at their full lifetime while most SIMDs are
 // already idle (8192 envs = 4 rounds of 2048 slots: ~20 % of the launch); shorter units shorten that drain.
 struct Sched {
-  int* ticket;          // [2]: counter of launch `launch_id & 1`; the wave that draws ticket 0 zeroes the other one
+  int* ticket;          // [2]: counter of launch `launch_id & 1` (tickets from min(gridDim.x, n_whole) on; below that a wave's first
+                        //      ticket is its workgroup index); workgroup 0 zeroes the other one
   int* err;             // [2]: hand-off waits that timed out since the batch was created (sticky), and the env of the last one
   unsigned* flags;      // [n]: (launch_id << 8) | phases of the env completed in this launch | RSR_FLAG_ERR
   unsigned launch_id;   // 1, 2, ... per rsr_step of the batch
-  int units;            // phases per env-step (1 = the whole step in one unit), at most RSR_MAX_UNITS
+  int units;            // phases per env-step of the envs that are split (1 = the whole step in one unit), at most RSR_MAX_UNITS
+  int n_whole;          // envs [0, n_whole) are stepped as one unit each whatever `units` says (rsr_batch_set_whole_envs)
   int spin_cap;         // bound of the hand-off poll (sleeps of 8 x 64 cycles); test hook: rsr_batch_set_fault_injection
   int withhold_env;     // test hook: phase 0 of this env never publishes its flag (-1: none)
 };

@@ -457,9 +457,6 @@ __global__ __launch_bounds__(64) void reset_kernel(const DModel* __restrict__ mp
 #ifndef RSR_WAVES_PER_EU
 #define RSR_WAVES_PER_EU 2
 #endif
-#ifndef RSR_PERSISTENT
-#define RSR_PERSISTENT 1             // 1: a wave loops over tickets; 0: one ticket per workgroup, grid = units * n (measured: DESIGN.md 4)
-#endif
 #ifndef RSR_DEFAULT_UNITS
 #define RSR_DEFAULT_UNITS 4          // phases per env-step of the work-queue dispatch (measured: DESIGN.md 4)
 #endif
@@ -473,23 +470,48 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   const int lane = threadIdx.x;
   const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
   constexpr int JQ = ENV == ENV_TSHAPE ? (int)TID_JOINTQ : (int)ID_JOINTQ;
-  const int units = sc.units, total = units * a.n;
+  // Ticket space: the first n_whole envs are stepped as ONE unit each (all substeps: no hand-off, no flag, one ticket), the rest
+  // as `units` phases each, phase-major.  Long units first, short units last: the launch still drains in short units, and only the
+  // envs that start late pay the per-unit overhead (ticket round trip, flag poll, state round trip through memory, store drain).
+  const int units = sc.units, n_whole = sc.n_whole, n_split = a.n - n_whole, total = n_whole + units * n_split;
   int* const ticket = sc.ticket + (sc.launch_id & 1u);
-  for (;;) {                                                   // persistent wave: one work unit (env, phase) per trip
-  // (Drawing the next unit's ticket at the start of the current one hides the atomic's round trip but binds the last units of a
-  // launch to waves that are still busy while others idle: measured -3.4 % on the cube.)
-  int tk = 0;
-  if (lane == 0) {
-    tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == 0) __hip_atomic_store(sc.ticket + ((sc.launch_id + 1u) & 1u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's counter
-  }
-  tk = uniform_i(tk);
+  // A wave's first ticket is its workgroup index where that ticket is a whole-env unit (which nobody waits for) -- 2048 waves
+  // drawing from one counter at launch serialise at ~90 atomics per microsecond, ~20 us before the last wave has its first
+  // unit -- and the counter hands out the tickets from n_static on.  (Tickets of split envs are only ever drawn from the counter,
+  // in dependency order, so the wave that holds (env, phase - 1) is running whatever the residency of the grid.)
+  const int n_static = (int)gridDim.x < n_whole ? (int)gridDim.x : n_whole;
+  if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(sc.ticket + ((sc.launch_id + 1u) & 1u), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's counter
+  auto draw = [&]() {
+    int t = 0;
+    if (lane == 0) t = n_static + __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  int tk_next = (int)blockIdx.x < n_static ? (int)blockIdx.x : draw();
+  for (;;) {                                                   // persistent wave: one work unit per trip
+  // The next unit's ticket is drawn when the current unit's substeps are done, ahead of its stores / epilogue: the atomic's round
+  // trip (~2 us under load, 16 units per wave and launch) overlaps them.  (Drawn at the START of the current unit it binds the
+  // last units of a launch to waves that are still busy for a whole unit while others idle: measured -3.4 % on the cube.)
+  const int tk = uniform_i(tk_next);
   if (tk >= total) break;                                      // every wave reaches this: the queue only drains
-  const int phase = tk / a.n, e = tk - phase * a.n;
-  const bool first = phase == 0, last = phase == units - 1;
+  int phase = 0, e = tk, eu = 1;                               // eu = units of this env's class
+  if (tk >= n_whole) { const int t2 = tk - n_whole; phase = t2 / n_split; e = n_whole + (t2 - phase * n_split); eu = units; }
+  const bool first = phase == 0, last = phase == eu - 1;
   float* rec = a.state + (size_t)e * L.rec;
   PROF_DECL
   // ---- load the record ----
+  // what no other unit of this launch writes first: the per-env model leaves and the env's bookkeeping words, so that their round
+  // trip overlaps the flag poll below
+  load_overrides<C>(m, s, a, e, lane);
+  const float done_prev = rec[L.done];
+  float steps = rec[L.steps];
+  if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;     // AutoResetWrapper.step pre-step
+  // env info read before it is updated
+  float tp[3] = {0, 0, 0}, aux_old[2];
+  if constexpr (ENV == ENV_TSHAPE) { aux_old[0] = rec[L.new_T_pos]; aux_old[1] = rec[L.new_T_pos + 1]; }
+  else {
+    tp[0] = rec[L.target_pos]; tp[1] = rec[L.target_pos + 1]; tp[2] = rec[L.target_pos + 2];
+    aux_old[0] = rec[L.new_cube_pos]; aux_old[1] = rec[L.new_cube_pos + 1];
+  }
   float warm = 0.0f, time;
   unsigned handoff_err = 0u;
   if (first) {
@@ -515,17 +537,6 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
     if (lane < C::NV) { s.qvel[lane] = ld_sc1(&rec[L.qvel + lane]); warm = ld_sc1(&rec[L.warm + lane]); }
     if (lane < C::NU) s.ctrl[lane] = ld_sc1(&rec[L.ctrl + lane]);
     time = ld_sc1(&rec[L.time]);
-  }
-  load_overrides<C>(m, s, a, e, lane);
-  const float done_prev = rec[L.done];
-  float steps = rec[L.steps];
-  if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;     // AutoResetWrapper.step pre-step
-  // env info read before it is updated
-  float tp[3] = {0, 0, 0}, aux_old[2];
-  if constexpr (ENV == ENV_TSHAPE) { aux_old[0] = rec[L.new_T_pos]; aux_old[1] = rec[L.new_T_pos + 1]; }
-  else {
-    tp[0] = rec[L.target_pos]; tp[1] = rec[L.target_pos + 1]; tp[2] = rec[L.target_pos + 2];
-    aux_old[0] = rec[L.new_cube_pos]; aux_old[1] = rec[L.new_cube_pos + 1];
   }
   // ---- prologue: ctrl shaping; uses the stale xpos / site_xpos of the previous forward pass ----
   if (first && lane < C::NU) {
@@ -561,7 +572,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
   // ---- n_frames x mjx.step ----
   float Mrow[C::NV];
   FwdOut<C> f;
-  for (int fr = phase * hot.n_frames / units; fr < (phase + 1) * hot.n_frames / units; ++fr) {
+  for (int fr = phase * hot.n_frames / eu; fr < (phase + 1) * hot.n_frames / eu; ++fr) {
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
 #else
@@ -574,6 +585,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
     integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
     time += hot.timestep;
   }
+  tk_next = draw();
   if (!last) {
     // hand the pipeline state to the next phase: write-through stores, drained, then the flag (one wave = one workgroup)
     for (int t = lane; t < C::NQ; t += 64) st_sc1(&rec[L.qpos + t], s.qpos[t]);
@@ -586,7 +598,6 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300 + 8 * phase, prof_rt0_, prof_ct0_);
 #endif
-    if (!RSR_PERSISTENT) break;
     WSYNC();
     continue;
   }
@@ -712,7 +723,6 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
   if (a.debug && lane == 0) prof_timeline(a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7300 + 8 * phase, prof_rt0_, prof_ct0_);
 #endif
-  if (!RSR_PERSISTENT) break;
   WSYNC();                                                     // the next unit reuses this wave's LDS image
   }
 }
@@ -1268,6 +1278,7 @@ struct rsr_batch {
   unsigned launch_id;
   int units, step_grid;
   int spin_cap, withhold_env;   // rsr_batch_set_fault_injection (test hook)
+  int whole_envs;               // rsr_batch_set_whole_envs: envs stepped as one unit each (-1: all but two resident rounds' worth)
 };
 
 static Layout make_layout(const rsr_dims& d) {
@@ -1534,7 +1545,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     if (ce != hipSuccess) { release(); return fail(RSR_ERR_HIP, std::string("rsr_batch_create: hipMemcpy(model): ") + hipGetErrorString(ce)); } }
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { release(); return rc; }
-  b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1;
+  b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1; b->whole_envs = -1;
   if (m->dims.env_kind != rsr::ENV_GO2) {
     const size_t sb = (4 + (size_t)num_envs) * sizeof(int);
     if (hipMalloc(&b->sched, sb) != hipSuccess) { b->sched = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
@@ -1552,6 +1563,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     if (b->units < 1) b->units = 1;
     if (b->units > m->dims.n_frames) b->units = m->dims.n_frames;
     if (b->units > RSR_MAX_UNITS) b->units = RSR_MAX_UNITS;
+    if (const char* wv = std::getenv("RSR_WHOLE_ENVS")) b->whole_envs = std::atoi(wv);      // diagnostic (tools/ab_bench.py)
   }
   if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { b->dmodel = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
   { hipError_t ce = hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice);
@@ -1599,6 +1611,12 @@ extern "C" int rsr_batch_set_schedule(rsr_batch* b, int units) {
   if (!b || units < 1) return fail(RSR_ERR_ARG, "rsr_batch_set_schedule: bad argument");
   b->units = units > b->model->dims.n_frames ? b->model->dims.n_frames : units;
   if (b->units > RSR_MAX_UNITS) b->units = RSR_MAX_UNITS;
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs) {
+  if (!b || whole_envs > b->n) return fail(RSR_ERR_ARG, "rsr_batch_set_whole_envs: bad argument");
+  b->whole_envs = whole_envs < 0 ? -1 : whole_envs;
   return RSR_OK;
 }
 
@@ -1669,9 +1687,13 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
       ++b->launch_id;
       HIPCHK(hipMemsetAsync(b->sched + 4, 0, (size_t)b->n * sizeof(int), st));
     }
-    rsr::Sched sc{b->sched, b->sched + 2, reinterpret_cast<unsigned*>(b->sched + 4), b->launch_id, b->units, b->spin_cap, b->withhold_env};
-    const long long work = (long long)b->units * b->n;
-    const int grid = (int)(RSR_PERSISTENT && work > b->step_grid ? b->step_grid : work);
+    // envs stepped as one unit: by default all but two resident rounds' worth (the launch then still drains in short units, with
+    // a slack of two resident rounds between the phases of a split env)
+    int n_whole = b->units <= 1 ? b->n : (b->whole_envs >= 0 ? b->whole_envs : (b->n > 2 * b->step_grid ? b->n - 2 * b->step_grid : 0));
+    if (n_whole > b->n) n_whole = b->n;
+    rsr::Sched sc{b->sched, b->sched + 2, reinterpret_cast<unsigned*>(b->sched + 4), b->launch_id, b->units, n_whole, b->spin_cap, b->withhold_env};
+    const long long work = (long long)n_whole + (long long)b->units * (b->n - n_whole);
+    const int grid = (int)(work > b->step_grid ? b->step_grid : work);
     if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
       hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                          b->dmodel, b->model->layout, a, sc);

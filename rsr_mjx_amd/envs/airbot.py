@@ -235,6 +235,10 @@ class BatchedEnv:
         """Work units per env-step of the persistent step launch (results are bit-identical for every value)."""
         _lib.check(_lib.lib().rsr_batch_set_schedule(self._batch, int(units)))
 
+    def set_whole_envs(self, whole_envs: int = -1) -> None:
+        """Envs stepped as one work unit each, the rest in `units` phases (rsr_batch_set_whole_envs; -1 = the default split)."""
+        _lib.check(_lib.lib().rsr_batch_set_whole_envs(self._batch, int(whole_envs)))
+
     def rollout_metrics(self, out=None):
         """One launch: float tensor [4] = (num_envs, sum of reward, sum of done, mean of the running episodes' summed reward) of
         this batch (rsr_rollout_metrics); needs the Episode wrapper's bookkeeping for the last entry."""

@@ -531,7 +531,9 @@ def test_schedule_changes_are_bit_identical(kind):
     """include/rsr_mjx.h, rsr_batch_set_schedule: "bit-identical for every value and for any sequence of values between
     steps".  One batch runs every step as one unit; the other changes units between steps of ONE rollout -- among them the
     4 -> 3 and 4 -> 1 -> 1 -> 2 orders in which a flag word that depended on `units` would meet a stale equal value -- across
-    truncation and auto-reset (episode_length 7).  Records are compared as int32 after every step; no hand-off wait times out."""
+    truncation and auto-reset (episode_length 7) -- and moves the boundary between the envs stepped as one unit and the envs cut
+    into phases (rsr_batch_set_whole_envs) at every step.  Records are compared as int32 after every step; no hand-off wait
+    times out."""
     import torch
     from rsr_mjx_amd import prng
     n, steps = 2048, 30
@@ -541,9 +543,10 @@ def test_schedule_changes_are_bit_identical(kind):
     gen = torch.Generator(device="cuda"); gen.manual_seed(3)
     acts = torch.clamp(torch.randn((steps, n, 5), generator=gen, device="cuda"), -1, 1)
     order = [4, 3, 2, 4, 1, 1, 2, 4, 4, 3, 1, 2, 2, 4, 3]
+    whole = [0, -1, 100, n // 2, n, 0, 1, n - 1, -1, 700]        # rsr_batch_set_whole_envs: envs stepped as one unit each
     a.set_schedule(1)
     for t in range(steps):
-        b.set_schedule(order[t % len(order)])
+        b.set_schedule(order[t % len(order)]); b.set_whole_envs(whole[t % len(whole)])
         a.step(None, acts[t]); b.step(None, acts[t])
         assert torch.equal(a.record.view(torch.int32), b.record.view(torch.int32)), (kind, "step", t, "units", order[t % len(order)])
     assert float(a.view("info_truncation").sum()) >= 0 and float(a.view("info_steps").max()) <= 7.0

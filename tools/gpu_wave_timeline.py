@@ -34,22 +34,43 @@ dbg = env.enable_debug(True)
 for t in range(60):
     env.step(s, torch.clamp(torch.randn(n, nu, device="cuda") * astd, -1, 1))
 torch.cuda.synchronize()
+whole = int(sys.argv[sys.argv.index("--whole") + 1]) if "--whole" in sys.argv else None
+if whole is not None:
+    env.set_whole_envs(whole)
+    dbg.zero_()
+    for t in range(3):
+        env.step(s, torch.clamp(torch.randn(n, nu, device="cuda") * astd, -1, 1))
+    torch.cuda.synchronize()
 raw = dbg[:, 7300:7300 + 8 * units].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
 raw = raw.reshape(n, units, 8).transpose(1, 0, 2).reshape(n * units, 8)        # unit-major: all phase-0 units, then phase 1, ...
 rt0 = raw[:, 0] | (raw[:, 1] << 32); rt1 = raw[:, 2] | (raw[:, 3] << 32)
 cyc = raw[:, 4]; hw = raw[:, 5]; xcc = raw[:, 6] & 0xF
-if units > 1:
+if whole is not None:
+    # envs stepped as one unit write slot 0 only: keep the units that ran in the last launch
+    ran = rt0 >= rt0[rt0 > 0].max() - 300000            # within 3 ms of the latest start
+    is_whole = np.tile(np.arange(n) < (whole if whole >= 0 else 0), units)
+    for name, sel in (("whole-step units", ran & is_whole), ("split units", ran & ~is_whole)):
+        if sel.any():
+            print(f"{name}: {int(sel.sum())}, lifetime mean {((rt1[sel] - rt0[sel]) / 100.0).mean():.1f} us p99 {np.percentile((rt1[sel] - rt0[sel]) / 100.0, 99):.1f}, start {((rt0[sel] - rt0[ran].min()) / 100.0).min():.1f}..{((rt0[sel] - rt0[ran].min()) / 100.0).max():.1f} us")
+    rt0, rt1, cyc, hw, xcc = rt0[ran], rt1[ran], cyc[ran], hw[ran], xcc[ran]
+    stats_sel = ran
+elif units > 1:
+    stats_sel = None
     for ph in range(units):
         sl = slice(ph * n, (ph + 1) * n)
         print(f"phase {ph}: unit start {((rt0[sl] - rt0.min()) / 100.0).min():.1f}..{((rt0[sl] - rt0.min()) / 100.0).max():.1f} us, lifetime mean {((rt1[sl] - rt0[sl]) / 100.0).mean():.1f} us, cycles mean {cyc[sl].mean():.0f}")
     gap = (rt0[n:2 * n] - rt1[:n]) / 100.0
     print(f"phase 1 start minus phase 0 end of the same env: min {gap.min():.1f} p50 {np.median(gap):.1f} max {gap.max():.1f} us")
+else:
+    stats_sel = None
 t0 = (rt0 - rt0.min()) / 100.0; t1 = (rt1 - rt0.min()) / 100.0      # microseconds (100 MHz)
 life = t1 - t0
 print(f"envs {n}: makespan {t1.max():.1f} us; first start spread {t0.min():.1f}..{np.percentile(t0, 25):.1f} us (25% of waves)")
 print("wave lifetime us: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f mean %.1f" % (life.min(), *np.percentile(life, [10, 50, 90, 99]), life.max(), life.mean()))
 print("wave shader cycles: p50 %.0f mean %.0f max %.0f ; implied clock GHz p50 %.2f" % (np.median(cyc), cyc.mean(), cyc.max(), np.median(cyc / life) / 1e3))
 stats = np.tile(env.view("stats").cpu().numpy(), (units, 1))
+if stats_sel is not None:
+    stats = stats[stats_sel]
 ncon = stats[:, 2]
 for lo, hi in ((0, 4), (5, 8), (9, 12), (13, 16), (17, 99)):
     sel = (ncon >= lo) & (ncon <= hi)
@@ -60,7 +81,7 @@ grid = np.linspace(0, t1.max(), 41)
 res = [(np.sum((t0 <= g) & (t1 > g))) for g in grid]
 print("waves in flight at 2.5% steps of the makespan:", " ".join(str(r) for r in res))
 order = np.argsort(t0)
-print("start time of wave rank 2048/4096/6144/8191: " + " ".join(f"{t0[order[min(k, n * units - 1)]]:.1f}" for k in (2048, 4096, 6144, 8191)))
+print("start time of wave rank 2048/4096/6144/8191: " + " ".join(f"{t0[order[min(k, len(t0) - 1)]]:.1f}" for k in (2048, 4096, 6144, 8191)))
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; se = (hw >> 13) & 7
 slot = ((xcc * 8 + se) * 16 + cu) * 4 + simd
 u, c = np.unique(slot, return_counts=True)
@@ -71,7 +92,7 @@ for i, sl in enumerate(u):
 print("per-SIMD sum of wave lifetimes / (2 x makespan): mean %.3f min %.3f max %.3f" % ((busy / (2 * t1.max())).mean(), (busy / (2 * t1.max())).min(), (busy / (2 * t1.max())).max()))
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "timeline.npz"), t0=t0, t1=t1, cyc=cyc, hw=hw, xcc=xcc, stats=stats)
 
-if units > 1:
+if units > 1 or whole is not None:
     sys.exit(0)
 # ---- how well does the previous step's lifetime predict this step's (longest-first dispatch keyed on it)?
 import heapq
