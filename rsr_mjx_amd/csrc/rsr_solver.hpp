@@ -77,7 +77,15 @@ __device__ __forceinline__ float rows_cost(int lane, int nefc, const float (&jar
   return REDUCE ? wave_sum(cost) : cost;      // !REDUCE: this lane's share, for a caller that reduces several sums together
 }
 
-struct LSPoint { float alpha, cost, d0, d1; };
+// One step size of a line search: the 1-D model's derivatives there, and the summed linear / quadratic coefficients from which
+// the cost is formed once the search has ended (ls_costs).
+// (The derivatives are functions of three numbers and are formed where they are read: the line-search loop is the kernel's register
+// peak, and its six points are wave-uniform values in vector registers.)
+struct LSPoint {
+  float alpha, q1, q2;
+  __device__ __forceinline__ float d0() const { return 2.0f * alpha * q2 + q1; }
+  __device__ __forceinline__ float d1() const { return 2.0f * q2 + (q2 == 0.0f ? RSR_MINVAL : 0.0f); }
+};
 
 // Per-row constants of one line search (they do not depend on the step size): the quadratic piece b0 + b1 a + b2 a^2 of an
 // active row, and for the first chunk -- the only one that can hold equality and friction rows -- the two linear pieces
@@ -109,24 +117,26 @@ __device__ __forceinline__ void ls_prepare(int lane, int nefc, const float (&jar
   if (lane >= nefc) { o.tlo = INFINITY; o.thi = INFINITY; }
 }
 
-// Evaluates the 1-D cost model at NPT step sizes at once: per-row pieces are summed over the rows owned by the lane, then
-// the 3*NPT partial sums are reduced together (independent DPP chains overlap).
+// The 1-D model's derivatives at NPT step sizes at once: the linear and quadratic pieces of the rows owned by the lane are summed,
+// then the 2*NPT partial sums are reduced three chains at a time (independent DPP chains overlap).  The constant pieces -- the
+// cost itself -- are NOT summed here: the bracket update only looks at derivatives, and the cost is needed for three step sizes of
+// a search (its start and its two final ends), not for the three candidates of every iteration (ls_costs; a third of the row
+// work and of the reductions of an iteration before).
 template <class C, int NPT>
-__device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], const LSRows<C>& w, float g0, float g1, float g2,
-                                        LSPoint (&out)[NPT]) {
-  float q[NPT][3];
+__device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], const LSRows<C>& w, float g1, float g2, LSPoint (&out)[NPT]) {
+  static_assert(NPT == 1 || NPT == 3, "one step size or the three candidates of an iteration");
+  float q[NPT][2];
   // (copies first: a ?: between struct members is an lvalue select, which would pin the struct in scratch memory)
-  const float ja0 = w.ja[0], v0 = w.v[0], tlo = w.tlo, thi = w.thi, c0m = w.c0m, c0p = w.c0p, c1m = w.c1m, c1p = w.c1p;
-  const float b00 = w.b0[0], b10 = w.b1[0], b20 = w.b2[0];
+  const float ja0 = w.ja[0], v0 = w.v[0], tlo = w.tlo, thi = w.thi, c1m = w.c1m, c1p = w.c1p;
+  const float b10 = w.b1[0], b20 = w.b2[0];
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
     // chunk 0: three pieces
     float x = ja0 + alpha[p] * v0;
     bool lo = x <= -tlo, hi = x >= thi;
-    float u0 = hi ? c0p : b00, u1 = hi ? c1p : b10;
-    q[p][0] = lo ? c0m : u0;
-    q[p][1] = lo ? c1m : u1;
-    q[p][2] = (lo || hi) ? 0.0f : b20;
+    float u1 = hi ? c1p : b10;
+    q[p][0] = lo ? c1m : u1;
+    q[p][1] = (lo || hi) ? 0.0f : b20;
   }
 #pragma unroll
   for (int ch = 1; ch < C::NCHUNK; ++ch) {
@@ -135,26 +145,52 @@ __device__ __forceinline__ void ls_eval(int nefc, const float (&alpha)[NPT], con
     for (int p = 0; p < NPT; ++p) {           // unilateral rows only: quadratic while x < 0
       float x = w.ja[ch] + alpha[p] * w.v[ch];
       bool act = x < 0.0f;
-      q[p][0] += act ? w.b0[ch] : 0.0f; q[p][1] += act ? w.b1[ch] : 0.0f; q[p][2] += act ? w.b2[ch] : 0.0f;
+      q[p][0] += act ? w.b1[ch] : 0.0f; q[p][1] += act ? w.b2[ch] : 0.0f;
     }
   }
-#pragma unroll
-  for (int p = 0; p < NPT; ++p) wave_sum3(q[p][0], q[p][1], q[p][2]);
+  if constexpr (NPT == 3) { wave_sum3(q[0][0], q[1][0], q[2][0]); wave_sum3(q[0][1], q[1][1], q[2][1]); }
+  else { float z = 0.0f; wave_sum3(q[0][0], q[0][1], z); }
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
-    float q0 = q[p][0] + g0, q1 = q[p][1] + g1, q2 = q[p][2] + g2, al = alpha[p];
-    out[p].alpha = al;
-    out[p].cost = al * al * q2 + al * q1 + q0;
-    out[p].d0 = 2.0f * al * q2 + q1;
-    out[p].d1 = 2.0f * q2 + (q2 == 0.0f ? RSR_MINVAL : 0.0f);
+    float q1 = q[p][0] + g1, q2 = q[p][1] + g2, al = alpha[p];
+    out[p].alpha = al; out[p].q1 = q1; out[p].q2 = q2;
   }
 }
 template <class C>
-__device__ __forceinline__ LSPoint ls_point(int nefc, float alpha, const LSRows<C>& w, float g0, float g1, float g2) {
+__device__ __forceinline__ LSPoint ls_point(int nefc, float alpha, const LSRows<C>& w, float g1, float g2) {
   float al[1] = {alpha};
   LSPoint o[1];
-  ls_eval<C, 1>(nefc, al, w, g0, g1, g2, o);
+  ls_eval<C, 1>(nefc, al, w, g1, g2, o);
   return o[0];
+}
+// Cost of the 1-D model at three points that have been evaluated: the constant pieces of the rows at each step size, one
+// reduction for the three, and al^2 q2 + al q1 + q0 with the point's own q1 / q2 (the same sums, the same expression, the same
+// bits as when every evaluation carried its cost along).
+template <class C>
+__device__ __forceinline__ void ls_costs(int nefc, const LSRows<C>& w, float g0, const LSPoint& a, const LSPoint& b, const LSPoint& c,
+                                         float& cost_a, float& cost_b, float& cost_c) {
+  const float al[3] = {a.alpha, b.alpha, c.alpha};
+  float q0[3];
+  const float ja0 = w.ja[0], v0 = w.v[0], tlo = w.tlo, thi = w.thi, c0m = w.c0m, c0p = w.c0p, b00 = w.b0[0];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    float x = ja0 + al[p] * v0;
+    bool lo = x <= -tlo, hi = x >= thi;
+    float u0 = hi ? c0p : b00;
+    q0[p] = lo ? c0m : u0;
+  }
+#pragma unroll
+  for (int ch = 1; ch < C::NCHUNK; ++ch) {
+    if (64 * ch >= nefc) continue;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      float x = w.ja[ch] + al[p] * w.v[ch];
+      q0[p] += x < 0.0f ? w.b0[ch] : 0.0f;
+    }
+  }
+  wave_sum3(q0[0], q0[1], q0[2]);
+  auto cost = [&](const LSPoint& pt, float s0) { const float q0s = s0 + g0, q1 = pt.q1, q2 = pt.q2, a_ = pt.alpha; return a_ * a_ * q2 + a_ * q1 + q0s; };
+  cost_a = cost(a, q0[0]); cost_b = cost(b, q0[1]); cost_c = cost(c, q0[2]);
 }
 
 // qfrc_constraint = J^T force.  Friction and limit rows have one +-1 entry: their force goes straight to that dof (one LDS
@@ -509,10 +545,11 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     LSRows<C> lw;
     ls_prepare<C>(lane, nefc, jaref, jv, rr, lw);
     PROF(PS_L_PREP)
-    LSPoint p0 = ls_point<C>(nefc, 0.0f, lw, gauss, g1, g2);
+    LSPoint p0 = ls_point<C>(nefc, 0.0f, lw, g1, g2);
     PROF(PS_L_P0)
-    LSPoint lo = ls_point<C>(nefc, p0.alpha - p0.d0 * __builtin_amdgcn_rcpf(p0.d1), lw, gauss, g1, g2), hi;
-    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    const float p0_d0 = p0.d0();
+    LSPoint lo = ls_point<C>(nefc, p0.alpha - p0_d0 * __builtin_amdgcn_rcpf(p0.d1()), lw, g1, g2), hi;
+    if (lo.d0() < p0_d0) { hi = p0; } else { hi = lo; lo = p0; }
     PROF(PS_L_LO)
     bool swap = true; int it = 0;
     // Limit cycles of the bracket update, cut short exactly.  A Newton step from `lo` that overshoots is accepted as the new
@@ -536,37 +573,42 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
         hist_lo = dpp_mov<0x111>(hist_lo); hist_hi = dpp_mov<0x111>(hist_hi);                       // row_shr:1
         if (lane == 0) { hist_lo = lo.alpha; hist_hi = hi.alpha; }
       }
+      const float lo_d0 = lo.d0(), hi_d0 = hi.d0();
       bool ldone = it >= cap;
       ldone |= !swap;
       float tol_lo = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(lo.alpha) * n2));
       float tol_hi = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(hi.alpha) * n2));
       if (NOISE > 0.0f) {     // below the rounding noise of its own sum the derivative has no sign
-        ldone |= fabsf(lo.d0) < tol_lo;
-        ldone |= fabsf(hi.d0) < tol_hi;
+        ldone |= fabsf(lo_d0) < tol_lo;
+        ldone |= fabsf(hi_d0) < tol_hi;
       } else {
-        ldone |= (lo.d0 < 0.0f) && (lo.d0 > -tol_lo);
-        ldone |= (hi.d0 > 0.0f) && (hi.d0 < tol_hi);
+        ldone |= (lo_d0 < 0.0f) && (lo_d0 > -tol_lo);
+        ldone |= (hi_d0 > 0.0f) && (hi_d0 < tol_hi);
       }
       if (uniform_i(ldone)) break;
-      float al3[3] = {lo.alpha - lo.d0 * __builtin_amdgcn_rcpf(lo.d1), hi.alpha - hi.d0 * __builtin_amdgcn_rcpf(hi.d1), 0.5f * (lo.alpha + hi.alpha)};
+      float al3[3] = {lo.alpha - lo_d0 * __builtin_amdgcn_rcpf(lo.d1()), hi.alpha - hi_d0 * __builtin_amdgcn_rcpf(hi.d1()), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
-      ls_eval<C, 3>(nefc, al3, lw, gauss, g1, g2, p3);
-      LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
-      bool s1 = (lo.d0 > 0.0f) || (lo.d0 < lo_next.d0);
-      if (s1) lo = lo_next;
-      bool s2 = (mid.d0 < 0.0f) && (lo.d0 < mid.d0);
+      ls_eval<C, 3>(nefc, al3, lw, g1, g2, p3);
+      const LSPoint lo_next = p3[0], hi_next = p3[1], mid = p3[2];
+      const float mid_d0 = mid.d0();
+      float lo_cur = lo_d0, hi_cur = hi_d0;                   // d0 of the ends as the four updates go along
+      bool s1 = (lo_cur > 0.0f) || (lo_cur < lo_next.d0());
+      if (s1) { lo = lo_next; lo_cur = lo_next.d0(); }
+      bool s2 = (mid_d0 < 0.0f) && (lo_cur < mid_d0);
       if (s2) lo = mid;
-      bool s3 = (hi.d0 < 0.0f) || (hi.d0 > hi_next.d0);
-      if (s3) hi = hi_next;
-      bool s4 = (mid.d0 > 0.0f) && (hi.d0 > mid.d0);
+      bool s3 = (hi_cur < 0.0f) || (hi_cur > hi_next.d0());
+      if (s3) { hi = hi_next; hi_cur = hi_next.d0(); }
+      bool s4 = (mid_d0 > 0.0f) && (hi_cur > mid_d0);
       if (s4) hi = mid;
       swap = s1 | s2 | s3 | s4;
       ++it;
     }
     ls_total += it;
     PROF(PS_L_ITER)
-    bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-    float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    float cost_p0, cost_lo, cost_hi;
+    ls_costs<C>(nefc, lw, gauss, p0, lo, hi, cost_p0, cost_lo, cost_hi);
+    bool improved = (cost_lo < cost_p0) || (cost_hi < cost_p0);
+    float alpha = cost_lo < cost_hi ? lo.alpha : hi.alpha;
     if (improved) {
       qacc += alpha * search; Ma += alpha * mv;
 #pragma unroll
@@ -582,7 +624,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     wave_sum3(rc, gauss, unused);
     gauss *= 0.5f;
     prev_cost = cost; cost = rc + gauss;
-    if (dbg && lane == 0 && iter < 16) { dbg[7410 + 4 * iter] = cost; dbg[7411 + 4 * iter] = improved ? alpha : 0.0f; dbg[7412 + 4 * iter] = (float)it; dbg[7413 + 4 * iter] = p0.d0; }
+    if (dbg && lane == 0 && iter < 16) { dbg[7410 + 4 * iter] = cost; dbg[7411 + 4 * iter] = improved ? alpha : 0.0f; dbg[7412 + 4 * iter] = (float)it; dbg[7413 + 4 * iter] = p0_d0; }
     PROF(PS_X6)
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
