@@ -60,6 +60,9 @@ def _load(precision: str) -> C.CDLL:
     lib.oracle_uniform.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.oracle_box_box.argtypes = [C.c_void_p] * 8
     lib.oracle_plane_box.argtypes = [C.c_void_p] * 7
+    for prec_real in ((C.c_float if precision == "f32" else C.c_double),):
+        lib.oracle_plane_capsule.argtypes = [C.c_void_p] * 4 + [prec_real, prec_real] + [C.c_void_p] * 3
+        lib.oracle_plane_cylinder.argtypes = [C.c_void_p] * 4 + [prec_real, prec_real] + [C.c_void_p] * 2
     lib.oracle_hfield_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 

@@ -37,16 +37,16 @@ typedef RSR_REAL real;
 #define MAXIMP ((real)0.9999)
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
-enum { PAIR_PLANE_BOX = 0, PAIR_BOX_BOX = 1, PAIR_PLANE_SPHERE = 2, PAIR_HFIELD_SPHERE = 3 };
+enum { PAIR_PLANE_BOX = 0, PAIR_BOX_BOX = 1, PAIR_PLANE_SPHERE = 2, PAIR_HFIELD_SPHERE = 3, PAIR_PLANE_CAPSULE = 4, PAIR_PLANE_CYLINDER = 5 };
 enum { INT_EULER = 0, INT_IMPLICITFAST = 3 };
-enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
+enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3, ENV_GO2_HANDSTAND = 4 };
 
 #define NQ_MAX 32
 #define NV_MAX 24
 #define NU_MAX 12
 #define NBODY_MAX 16
 #define NJNT_MAX 16
-#define NGEOM_MAX 40
+#define NGEOM_MAX 48
 #define NSITE_MAX 8
 #define NKEY_MAX 8
 #define NPAIR_MAX 64
@@ -625,6 +625,71 @@ static int plane_sphere(const real *ppos, const real *pmat, const real *spos, re
   return 1;
 }
 
+/* capsule (geom2) vs plane (geom1): the two end spheres of the segment, +axis end first; both contacts share a frame whose first
+ * tangent follows the capsule axis projected into the plane (mujoco-mjx 3.2.x collision_primitive.plane_capsule, restated from
+ * its published source: "align contact frames with capsule axis"; not in the reference tree: parity unpinned).  frame: 9 floats. */
+static int plane_capsule(const real *ppos, const real *pmat, const real *cpos, const real *cmat, real radius, real halflen,
+                         cpoint *out, real *normal, real *frame) {
+  real n[3] = {pmat[2], pmat[5], pmat[8]}, axis[3] = {cmat[2], cmat[5], cmat[8]};
+  v3copy(normal, n);
+  real na = v3dot(n, axis), b[3] = {axis[0] - n[0] * na, axis[1] - n[1] * na, axis[2] - n[2] * na};
+  real bn = v3norm(b);
+  if (bn < (real)0.5) { if (n[1] > (real)-0.5 && n[1] < (real)0.5) v3set(b, 0, 1, 0); else v3set(b, 0, 0, 1); }
+  else for (int k = 0; k < 3; k++) b[k] /= bn;
+  real c[3];
+  v3cross(c, n, b);
+  for (int k = 0; k < 3; k++) { frame[k] = n[k]; frame[3 + k] = b[k]; frame[6 + k] = c[k]; }
+  for (int i = 0; i < 2; i++) {
+    real sg = i == 0 ? (real)1 : (real)-1, ctr[3];
+    for (int k = 0; k < 3; k++) ctr[k] = cpos[k] + sg * axis[k] * halflen;
+    real rel[3] = {ctr[0] - ppos[0], ctr[1] - ppos[1], ctr[2] - ppos[2]};
+    real dist = v3dot(rel, n) - radius;
+    out[i].dist = dist;
+    for (int k = 0; k < 3; k++) out[i].pos[k] = ctr[k] - n[k] * (radius + (real)0.5 * dist);
+  }
+  return 2;
+}
+
+/* cylinder (geom2) vs plane (geom1): three points of the rim of the disk that faces the plane -- the deepest one and two at
+ * +-120 degrees (scaled sqrt(3)/2 sideways, -1/2 along) -- or, when the cylinder lies parallel to the plane, the deepest rim points
+ * of both disks and one side point (mujoco-mjx 3.2.x collision_primitive.plane_cylinder, restated from its published source;
+ * parity unpinned).  size = (radius, half length). */
+static int plane_cylinder(const real *ppos, const real *pmat, const real *cpos, const real *cmat, real radius, real halflen,
+                          cpoint *out, real *normal) {
+  real n[3] = {pmat[2], pmat[5], pmat[8]}, axis[3] = {cmat[2], cmat[5], cmat[8]};
+  v3copy(normal, n);
+  real prjaxis = v3dot(n, axis);
+  real sign = prjaxis < 0 ? (real)1 : (real)-1;              /* make the axis point toward the plane */
+  for (int k = 0; k < 3; k++) axis[k] *= sign;
+  prjaxis *= sign;
+  real rel[3] = {cpos[0] - ppos[0], cpos[1] - ppos[1], cpos[2] - ppos[2]};
+  real dist0 = v3dot(rel, n);
+  real vec[3] = {axis[0] * prjaxis - n[0], axis[1] * prjaxis - n[1], axis[2] * prjaxis - n[2]};
+  real len = v3norm(vec);
+  if (len < (real)1e-12) for (int k = 0; k < 3; k++) vec[k] = cmat[3 * k] * radius;     /* disk parallel to the plane: the cylinder's x axis */
+  else for (int k = 0; k < 3; k++) vec[k] = vec[k] / len * radius;
+  real prjvec = v3dot(vec, n);
+  for (int k = 0; k < 3; k++) axis[k] *= halflen;
+  prjaxis *= halflen;
+  real prjvec1 = -prjvec * (real)0.5, vec1[3];
+  v3cross(vec1, vec, axis);
+  real l1 = v3norm(vec1);
+  for (int k = 0; k < 3; k++) vec1[k] = (l1 > 0 ? vec1[k] / l1 : 0) * radius * (real)sqrt(3.0) * (real)0.5;
+  real d1 = dist0 + prjaxis + prjvec, d2 = dist0 + prjaxis + prjvec1;
+  out[0].dist = d1; out[1].dist = d2; out[2].dist = d2;
+  for (int k = 0; k < 3; k++) {
+    out[0].pos[k] = cpos[k] + axis[k] + vec[k] - n[k] * d1 * (real)0.5;
+    out[1].pos[k] = cpos[k] + axis[k] + vec1[k] + vec[k] * (real)-0.5 - n[k] * d2 * (real)0.5;
+    out[2].pos[k] = cpos[k] + axis[k] - vec1[k] + vec[k] * (real)-0.5 - n[k] * d2 * (real)0.5;
+  }
+  if ((prjaxis < 0 ? -prjaxis : prjaxis) < (real)1e-3) {   /* cylinder parallel to the plane: the second point moves to the other disk */
+    real d3 = dist0 - prjaxis + prjvec;
+    out[1].dist = d3;
+    for (int k = 0; k < 3; k++) out[1].pos[k] = cpos[k] + vec[k] - axis[k] - n[k] * d3 * (real)0.5;
+  }
+  return 3;
+}
+
 /* closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5: Voronoi regions of the
  * vertices, edges and face) */
 static void closest_on_triangle(const real *p, const real *a, const real *b, const real *c, real *q) {
@@ -876,7 +941,7 @@ static void collision(const omodel *m, odata *d) {
   d->ncon = 0; d->ncon_overflow = 0;
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
-    cpoint pts[4]; real normal[3]; int n = 0;
+    cpoint pts[4]; real normal[3], cframe[9]; int n = 0, own_frame = 0;
     real s1[3] = {m->geom_size[3 * g1], m->geom_size[3 * g1 + 1], m->geom_size[3 * g1 + 2]};
     real s2[3] = {m->geom_size[3 * g2], m->geom_size[3 * g2 + 1], m->geom_size[3 * g2 + 2]};
     switch (m->pair_kind[p]) {
@@ -893,6 +958,13 @@ static void collision(const omodel *m, odata *d) {
         n = hfield_sphere(&d->geom_xpos[3 * g1], &d->geom_xmat[9 * g1], m->hfield_size, m->hfield_nrow[0], m->hfield_ncol[0], m->hfield_data,
                           &d->geom_xpos[3 * g2], s2[0], pts, normal);
         break;
+      case PAIR_PLANE_CAPSULE:
+        n = plane_capsule(&d->geom_xpos[3 * g1], &d->geom_xmat[9 * g1], &d->geom_xpos[3 * g2], &d->geom_xmat[9 * g2], s2[0], s2[1], pts, normal, cframe);
+        own_frame = 1;
+        break;
+      case PAIR_PLANE_CYLINDER:
+        n = plane_cylinder(&d->geom_xpos[3 * g1], &d->geom_xmat[9 * g1], &d->geom_xpos[3 * g2], &d->geom_xmat[9 * g2], s2[0], s2[1], pts, normal);
+        break;
       default: n = 0;
     }
     real includemargin = m->pair_margin[p] - m->pair_gap[p];
@@ -901,7 +973,7 @@ static void collision(const omodel *m, odata *d) {
       if (d->ncon >= g_ncon_cap) { d->ncon_overflow++; continue; }
       ocontact *c = &d->con[d->ncon++];
       c->dist = pts[i].dist; v3copy(c->pos, pts[i].pos);
-      make_frame(c->frame, normal);
+      if (own_frame) for (int k = 0; k < 9; k++) c->frame[k] = cframe[k]; else make_frame(c->frame, normal);
       c->includemargin = includemargin;
       c->body1 = m->geom_bodyid[g1]; c->body2 = m->geom_bodyid[g2];
       c->condim = m->pair_condim[p]; c->pair = p;
@@ -1611,7 +1683,7 @@ static void reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], 
   memcpy(&s->first_xpos[e * m->nbody * 3], xpos, sizeof(float) * (size_t)m->nbody * 3);
   memcpy(&s->first_site_xpos[e * m->nsite * 3], sx, sizeof(float) * (size_t)m->nsite * 3);
   memcpy(&s->first_obs[e * m->obs_dim], &s->obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
-  if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+  if ((m->env_kind == ENV_GO2 || m->env_kind == ENV_GO2_HANDSTAND) && s->priv_obs && s->first_priv_obs)
     memcpy(&s->first_priv_obs[(size_t)e * GO2_PRIV], &s->priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
 }
 
@@ -1714,7 +1786,7 @@ static void step_env(const omodel *m, obatch *s, int e, const float *action, oda
     memcpy(xpos, &s->first_xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
     memcpy(sx, &s->first_site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
     memcpy(&s->obs[e * m->obs_dim], &s->first_obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
-    if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+    if ((m->env_kind == ENV_GO2 || m->env_kind == ENV_GO2_HANDSTAND) && s->priv_obs && s->first_priv_obs)
       memcpy(&s->priv_obs[(size_t)e * GO2_PRIV], &s->first_priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
   }
 }
@@ -1748,7 +1820,7 @@ static void wrappers_reset(const omodel *m, obatch *s, int e) {
   memcpy(&s->first_xpos[e * m->nbody * 3], &s->xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
   memcpy(&s->first_site_xpos[e * m->nsite * 3], &s->site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
   memcpy(&s->first_obs[e * m->obs_dim], &s->obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
-  if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+  if ((m->env_kind == ENV_GO2 || m->env_kind == ENV_GO2_HANDSTAND) && s->priv_obs && s->first_priv_obs)
     memcpy(&s->first_priv_obs[(size_t)e * GO2_PRIV], &s->priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
 }
 
@@ -1778,7 +1850,7 @@ static void wrappers_post(const omodel *m, obatch *s, int e, float reward) {
     memcpy(&s->xpos[e * m->nbody * 3], &s->first_xpos[e * m->nbody * 3], sizeof(float) * (size_t)m->nbody * 3);
     memcpy(&s->site_xpos[e * m->nsite * 3], &s->first_site_xpos[e * m->nsite * 3], sizeof(float) * (size_t)m->nsite * 3);
     memcpy(&s->obs[e * m->obs_dim], &s->first_obs[e * m->obs_dim], sizeof(float) * (size_t)m->obs_dim);
-    if (m->env_kind == ENV_GO2 && s->priv_obs && s->first_priv_obs)
+    if ((m->env_kind == ENV_GO2 || m->env_kind == ENV_GO2_HANDSTAND) && s->priv_obs && s->first_priv_obs)
       memcpy(&s->priv_obs[(size_t)e * GO2_PRIV], &s->first_priv_obs[(size_t)e * GO2_PRIV], sizeof(float) * GO2_PRIV);
   }
 }
@@ -2255,9 +2327,199 @@ static void go2_step_env(const omodel *m, obatch *s, int e, const float *action,
   if ((m->wrap_flags & 2) != 0 && s->done[e] != 0) for (int c = 0; c < 3; c++) info[G2_XFRC + c] = 0.0f;   /* data <- first data */
 }
 
+
+/* ================================================================== Go2 Handstand / Footstand (go2/handstand.py)
+ * env_ids: 0 imu site, 1 floor geom, 2..13 the twelve "unwanted contact" geoms (:97-113), 14..15 the feet geoms of the contact cost
+ * (:115-118), 16 trunk body.  env_go2f: ctrl_dt, action_scale, noise level, scales joint_pos / joint_vel / gyro / gravity / linvel,
+ * init_from_crouch, energy_termination_threshold, z_des, desired forward vector (3).  env_go2i: joint_ids (6) of the pose cost.
+ * env_go2_scales: the eleven reward scales in config order.  env_go2_home: home qpos (19) | pre_recovery qpos (19).
+ * env_go2_soft: soft lower (12) | soft upper (12) joint limits.  info block: step at 0, last_act at 4..15, rng at 137. */
+enum { HS_STEP = 0, HS_LAST_ACT = 4, HS_OBS = 45, HS_PRIV = 94 };
+enum { HM_HEIGHT = 0, HM_ORIENT, HM_CONTACT, HM_ACTION_RATE, HM_TERM, HM_DOF_LIMITS, HM_TORQUES, HM_POSE, HM_STAY_STILL, HM_ENERGY, HM_DOF_ACC, HM_COUNT };
+
+static int hs_pair_touching(const omodel *m, const odata *d, int geom) {      /* collision.geoms_colliding(data, geom, floor) */
+  const int floor_g = m->env_ids[1];
+  for (int i = 0; i < d->ncon; i++) {
+    if (!(d->con[i].dist < 0)) continue;
+    int g1 = m->pair_geom1[d->con[i].pair], g2 = m->pair_geom2[d->con[i].pair];
+    if ((g1 == floor_g && g2 == geom) || (g2 == floor_g && g1 == geom)) return 1;
+  }
+  return 0;
+}
+
+/* handstand.py:196-263: obs["state"] (45) and obs["privileged_state"] (94); advances info.rng by five splits */
+static void hs_obs(const omodel *m, float *info, const float *qpos, const float *qvel, const g2_sensors *sn, float torso_height,
+                   float *obs, float *priv) {
+  const float *F = m->env_go2f, *home = m->env_go2_home;
+  uint32_t rng[2], ks[2][2];
+  g2_get_key(info, rng);
+  float zero = 0.0f, one = 1.0f, u[12];
+  float ngyro[3], ngrav[3], nlin[3], nq[12], nv[12];
+#define NOISE(dst, src, n, scale) do { \
+    oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1]; \
+    oracle_uniform(ks[1], n, &zero, &one, 0, u); \
+    for (int i_ = 0; i_ < n; i_++) { volatile float a_ = 2.0f * u[i_]; volatile float b_ = a_ - 1.0f; volatile float c_ = b_ * F[2]; \
+      volatile float e_ = c_ * (scale); dst[i_] = (src)[i_] + e_; } } while (0)
+  NOISE(ngyro, sn->gyro, 3, F[5]);
+  NOISE(ngrav, sn->gravity, 3, F[6]);
+  NOISE(nq, qpos + 7, 12, F[3]);
+  NOISE(nv, qvel + 6, 12, F[4]);
+  NOISE(nlin, sn->local_linvel, 3, F[7]);
+#undef NOISE
+  g2_set_key(info, rng);
+  for (int i = 0; i < 3; i++) { obs[i] = nlin[i]; obs[3 + i] = ngyro[i]; obs[6 + i] = ngrav[i]; }
+  for (int i = 0; i < 12; i++) { obs[9 + i] = nq[i] - home[7 + i]; obs[21 + i] = nv[i]; obs[33 + i] = info[HS_LAST_ACT + i]; }
+  if (priv) {
+    int k = 0;
+    for (int i = 0; i < HS_OBS; i++) priv[k++] = obs[i];
+    for (int i = 0; i < 3; i++) priv[k++] = sn->gyro[i];
+    for (int i = 0; i < 3; i++) priv[k++] = sn->accel[i];
+    for (int i = 0; i < 3; i++) priv[k++] = sn->local_linvel[i];
+    for (int i = 0; i < 3; i++) priv[k++] = sn->global_angvel[i];
+    for (int i = 0; i < 12; i++) priv[k++] = qpos[7 + i];
+    for (int i = 0; i < 12; i++) priv[k++] = qvel[6 + i];
+    for (int i = 0; i < 12; i++) priv[k++] = sn->act_force[i];
+    priv[k++] = torso_height;
+    for (; k < GO2_PRIV; k++) priv[k] = 0.0f;
+  }
+}
+
+/* the sensor block of the joystick env reads feet sites through env_ids[1..4]; this env has none there: the common part only */
+static void hs_read_sensors(const omodel *m, const odata *d, g2_sensors *o) {
+  const int imu = m->env_ids[0];
+  const real *R = &d->site_xmat[9 * imu];
+  real t[3], g[3] = {0, 0, -1};
+  memset(o, 0, sizeof(*o));
+  mat_tmulv(t, R, &d->site_angvel[3 * imu]); for (int c = 0; c < 3; c++) o->gyro[c] = (float)t[c];
+  mat_tmulv(t, R, &d->site_linvel[3 * imu]); for (int c = 0; c < 3; c++) o->local_linvel[c] = (float)t[c];
+  mat_tmulv(t, R, g); for (int c = 0; c < 3; c++) o->gravity[c] = (float)t[c];
+  for (int c = 0; c < 3; c++) {
+    o->upvector[c] = (float)R[3 * c + 2];
+    o->global_linvel[c] = (float)d->site_linvel[3 * imu + c];
+    o->global_angvel[c] = (float)d->site_angvel[3 * imu + c];
+  }
+  for (int u = 0; u < m->nu; u++) o->act_force[u] = (float)d->actuator_force[u];
+  for (int c = 0; c < 3; c++) o->accel[c] = (float)d->acc_site[c];
+}
+
+/* handstand.py:119-160 */
+static void handstand_reset_env(const omodel *m, obatch *s, int e, const uint32_t key[2], odata *d) {
+  const float *F = m->env_go2f;
+  float *info = &s->info_go2[(size_t)e * GO2_INFO];
+  memset(info, 0, sizeof(float) * GO2_INFO);
+  uint32_t rng[2] = {key[0], key[1]}, ks[2][2];
+  float qpos[NQ_MAX], qvel[NV_MAX];
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  const int crouch = g2_uniform1(ks[1], 0.0f, 1.0f) < F[8];            /* jax.random.bernoulli(key, p) = uniform(key) < p */
+  for (int i = 0; i < m->nq; i++) qpos[i] = m->env_go2_home[(crouch ? m->nq : 0) + i];
+  for (int i = 0; i < m->nv; i++) qvel[i] = 0;
+  float lo = -0.5f, hi = 0.5f, u[8];
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  oracle_uniform(ks[1], 2, &lo, &hi, 0, u);
+  qpos[0] += u[0]; qpos[1] += u[1];
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  float yaw = g2_uniform1(ks[1], -3.14f, 3.14f);
+  {
+    float sn = sinf(yaw * 0.5f), cs = cosf(yaw * 0.5f);
+    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]}, r[4] = {cs, 0.0f * sn, 0.0f * sn, 1.0f * sn};
+    qpos[3] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+    qpos[4] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+    qpos[5] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+    qpos[6] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+  }
+  oracle_split(rng, 2, &ks[0][0]); rng[0] = ks[0][0]; rng[1] = ks[0][1];
+  oracle_uniform(ks[1], 6, &lo, &hi, 0, u);
+  if (!crouch) for (int i = 0; i < 6; i++) qvel[i] = u[i];
+  s->time[e] = 0;
+  for (int i = 0; i < m->nq; i++) s->qpos[e * m->nq + i] = qpos[i];
+  for (int i = 0; i < m->nv; i++) { s->qvel[e * m->nv + i] = qvel[i]; s->qacc_warmstart[e * m->nv + i] = 0; }
+  for (int i = 0; i < m->nu; i++) s->ctrl[e * m->nu + i] = qpos[7 + i];
+  load_env(m, s, e, d);
+  d->acc_site_id = m->env_ids[0]; d->xfrc_body = 0;
+  forward(m, d);
+  store_pipeline(m, s, e, d);
+  g2_set_key(info, rng);
+  for (int i = 0; i < m->nmetrics; i++) s->metrics[e * m->nmetrics + i] = 0;
+  g2_sensors sn;
+  hs_read_sensors(m, d, &sn);
+  hs_obs(m, info, &s->qpos[e * m->nq], &s->qvel[e * m->nv], &sn, (float)d->site_xpos[3 * m->env_ids[0] + 2], &s->obs[e * m->obs_dim],
+         s->priv_obs ? &s->priv_obs[(size_t)e * GO2_PRIV] : NULL);
+  s->reward[e] = 0; s->done[e] = 0;
+  wrappers_reset(m, s, e);
+}
+
+/* handstand.py:161-195 with the rewards :264-342 */
+static void handstand_step_env(const omodel *m, obatch *s, int e, const float *action, odata *d) {
+  const float *F = m->env_go2f, *SC = m->env_go2_scales, *home = m->env_go2_home, *soft = m->env_go2_soft;
+  const int nu = m->nu;
+  float *info = &s->info_go2[(size_t)e * GO2_INFO];
+  const float *act = &action[e * nu];
+  if ((m->wrap_flags & 2) != 0) { if (s->done[e] != 0) s->info_steps[e] = 0; s->done[e] = 0; }
+  load_env(m, s, e, d);
+  for (int i = 0; i < nu; i++) { volatile float sc = act[i] * F[1]; d->ctrl[i] = s->ctrl[e * nu + i] + sc; }     /* state.data.ctrl + action * scale */
+  d->acc_site_id = m->env_ids[0]; d->xfrc_body = 0;
+  for (int f = 0; f < m->n_frames; f++) step_physics(m, d);
+  store_pipeline(m, s, e, d);
+  const float *qpos = &s->qpos[e * m->nq], *qvel = &s->qvel[e * m->nv];
+  g2_sensors sn;
+  hs_read_sensors(m, d, &sn);
+  int unwanted = 0, feet = 0;
+  for (int k = 0; k < 12; k++) unwanted |= hs_pair_touching(m, d, m->env_ids[2 + k]);
+  for (int k = 0; k < 2; k++) feet |= hs_pair_touching(m, d, m->env_ids[14 + k]);
+  const float torso_height = (float)d->site_xpos[3 * m->env_ids[0] + 2];
+  hs_obs(m, info, qpos, qvel, &sn, torso_height, &s->obs[e * m->obs_dim], s->priv_obs ? &s->priv_obs[(size_t)e * GO2_PRIV] : NULL);
+  /* termination (:188-195) */
+  float energy = 0;
+  for (int i = 0; i < 12; i++) energy += fabsf(sn.act_force[i]) * fabsf(qvel[6 + i]);
+  const float done = (sn.upvector[2] < -0.25f || unwanted || energy > F[9]) ? 1.0f : 0.0f;
+  /* rewards, unscaled (:264-290) */
+  float rw[HM_COUNT];
+  {
+    float h = torso_height < F[10] ? torso_height : F[10];
+    volatile float err = F[10] - h;
+    rw[HM_HEIGHT] = expf(-err / 1.0f);
+    const real *R = &d->site_xmat[9 * m->env_ids[0]];
+    float fwd[3] = {(float)R[0], (float)R[3], (float)R[6]};                 /* site_xmat @ [1, 0, 0] */
+    volatile float c0 = fwd[0] * F[11]; volatile float c1 = fwd[1] * F[12]; volatile float c2 = fwd[2] * F[13];
+    volatile float cd = c0 + c1; float cos_dist = cd + c2;
+    volatile float nrm = 0.5f * cos_dist; float nr = nrm + 0.5f;
+    rw[HM_ORIENT] = nr * nr;
+    rw[HM_CONTACT] = feet ? 1.0f : 0.0f;
+    float ar = 0, tq = 0, lim = 0, dacc = 0, pose = 0, en = 0;
+    for (int i = 0; i < 12; i++) {
+      volatile float da = act[i] - info[HS_LAST_ACT + i]; ar += da * da;
+      tq += sn.act_force[i] * sn.act_force[i];
+      float q = qpos[7 + i];
+      volatile float lo_ = q - soft[i]; volatile float hi_ = q - soft[12 + i];
+      lim += -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
+      float qa = (float)d->qacc[6 + i]; dacc += qa * qa;
+      en += fabsf(qvel[6 + i]) * fabsf(sn.act_force[i]);
+    }
+    for (int k = 0; k < 6; k++) { int j = m->env_go2i[k]; volatile float dq = qpos[7 + j] - home[7 + j]; pose += dq * dq; }
+    rw[HM_ACTION_RATE] = ar; rw[HM_TORQUES] = tq; rw[HM_TERM] = done; rw[HM_DOF_LIMITS] = lim; rw[HM_DOF_ACC] = dacc; rw[HM_POSE] = pose;
+    volatile float ss = qvel[0] * qvel[0] + qvel[1] * qvel[1];
+    rw[HM_STAY_STILL] = ss + qvel[5] * qvel[5];
+    rw[HM_ENERGY] = en;
+  }
+  /* scaled, summed in the order of the _get_reward dict, times dt, clipped (:171-176) */
+  static const int order[HM_COUNT] = {HM_HEIGHT, HM_ORIENT, HM_CONTACT, HM_ACTION_RATE, HM_TORQUES, HM_TERM, HM_DOF_LIMITS, HM_DOF_ACC, HM_POSE,
+                                      HM_STAY_STILL, HM_ENERGY};
+  float sc[HM_COUNT], total = 0;
+  for (int k = 0; k < HM_COUNT; k++) { volatile float v = rw[k] * SC[k]; sc[k] = v; }
+  for (int k = 0; k < HM_COUNT; k++) { volatile float t = total + sc[order[k]]; total = t; }
+  volatile float rdt = total * F[0];
+  float reward = rdt < 0.0f ? 0.0f : (rdt > 10000.0f ? 10000.0f : rdt);
+  info[HS_STEP] += 1.0f;
+  for (int i = 0; i < nu; i++) info[HS_LAST_ACT + i] = act[i];
+  float *met = &s->metrics[e * m->nmetrics];
+  for (int k = 0; k < HM_COUNT; k++) met[k] = sc[k];
+  s->reward[e] = reward; s->done[e] = done;
+  wrappers_post(m, s, e, reward);
+}
+
 /* ------------------------------------------------------------------ exported batch entry points */
 int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2 && m->env_kind != ENV_GO2_HANDSTAND) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -2270,6 +2532,7 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
     for (int e = 0; e < s->n; e++) {
       if (m->env_kind == ENV_TSHAPE) tshape_reset_env(m, s, e, &keys[2 * e], d);
       else if (m->env_kind == ENV_GO2) go2_reset_env(m, s, e, &keys[2 * e], d);
+      else if (m->env_kind == ENV_GO2_HANDSTAND) handstand_reset_env(m, s, e, &keys[2 * e], d);
       else reset_env(m, s, e, &keys[2 * e], d);
     }
     odata_free(d);
@@ -2278,7 +2541,7 @@ int oracle_reset(const omodel *m, obatch *s, const uint32_t *keys, int num_threa
 }
 
 int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads) {
-  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2) return -1;
+  if (m->env_kind != ENV_CUBE && m->env_kind != ENV_AIRBOT_SF && m->env_kind != ENV_TSHAPE && m->env_kind != ENV_GO2 && m->env_kind != ENV_GO2_HANDSTAND) return -1;
 #ifdef _OPENMP
   if (num_threads > 0) omp_set_num_threads(num_threads);
 #pragma omp parallel
@@ -2291,6 +2554,7 @@ int oracle_step(const omodel *m, obatch *s, const float *action, int num_threads
     for (int e = 0; e < s->n; e++) {
       if (m->env_kind == ENV_TSHAPE) tshape_step_env(m, s, e, action, d);
       else if (m->env_kind == ENV_GO2) go2_step_env(m, s, e, action, d);
+      else if (m->env_kind == ENV_GO2_HANDSTAND) handstand_step_env(m, s, e, action, d);
       else step_env(m, s, e, action, d);
     }
     odata_free(d);
@@ -2401,6 +2665,19 @@ int oracle_box_box(const real *pa, const real *Ra, const real *sa, const real *p
 int oracle_plane_box(const real *pp, const real *pm, const real *bp, const real *bm, const real *size, real *out, real *normal) {
   cpoint pts[4];
   int n = plane_box(pp, pm, bp, bm, size, pts, normal);
+  for (int i = 0; i < n; i++) { out[4 * i] = pts[i].dist; for (int c = 0; c < 3; c++) out[4 * i + 1 + c] = pts[i].pos[c]; }
+  return n;
+}
+int oracle_plane_capsule(const real *pp, const real *pm, const real *cp, const real *cm, real radius, real halflen, real *out /* [2][4] dist, pos */,
+                         real *normal, real *frame) {
+  cpoint pts[4];
+  int n = plane_capsule(pp, pm, cp, cm, radius, halflen, pts, normal, frame);
+  for (int i = 0; i < n; i++) { out[4 * i] = pts[i].dist; for (int c = 0; c < 3; c++) out[4 * i + 1 + c] = pts[i].pos[c]; }
+  return n;
+}
+int oracle_plane_cylinder(const real *pp, const real *pm, const real *cp, const real *cm, real radius, real halflen, real *out /* [3][4] */, real *normal) {
+  cpoint pts[4];
+  int n = plane_cylinder(pp, pm, cp, cm, radius, halflen, pts, normal);
   for (int i = 0; i < n; i++) { out[4 * i] = pts[i].dist; for (int c = 0; c < 3; c++) out[4 * i + 1 + c] = pts[i].pos[c]; }
   return n;
 }

@@ -11,7 +11,7 @@ import numpy as np
 
 from ..mjcf import CompiledModel
 
-ENV_CUBE, ENV_TSHAPE, ENV_AIRBOT_SF, ENV_GO2 = 0, 1, 2, 3
+ENV_CUBE, ENV_TSHAPE, ENV_AIRBOT_SF, ENV_GO2, ENV_GO2_HANDSTAND = 0, 1, 2, 3, 4
 WRAP_EPISODE, WRAP_AUTORESET = 1, 2
 
 CUBE_DEFAULTS = dict(
@@ -208,6 +208,68 @@ def go2_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto
         env_go2_home=home,
         env_go2_soft=soft,
         # unused by this env kind but looked up by the generic loaders
+        env_action_scale=np.zeros(m.nu, np.float32), env_ctrl_lo=A["actuator_ctrlrange"][:, 0].astype(np.float32),
+        env_ctrl_hi=A["actuator_ctrlrange"][:, 1].astype(np.float32), env_reset=np.zeros(1, np.float32),
+        env_reward=np.zeros(1, np.float32),
+    )
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Go2 Handstand / Footstand: reference mujoco_playground/_src/locomotion/go2/handstand.py:13-52 (default_config), :53-118 (_post_init),
+# :293-342 (Footstand).  Model: scene_mjx_flat_terrain.xml -> go2_mjx.xml (every collision geom of the robot against the floor:
+# 4 spheres, 20 capsules, 6 cylinders; assets/go2_full.npz).
+HANDSTAND_OBS_DIM = 45
+HANDSTAND_PRIV_OBS_DIM = 94
+# config order of reward_config.scales = order of the metrics dict (handstand.py:36-50, :144-146)
+HANDSTAND_REWARDS = ("height", "orientation", "contact", "action_rate", "termination", "dof_pos_limits", "torques", "pose",
+                     "stay_still", "energy", "dof_acc")
+HANDSTAND_METRICS = tuple(f"reward/{k}" for k in HANDSTAND_REWARDS)
+HANDSTAND_DEFAULT_CONFIG = dict(
+    ctrl_dt=0.02, sim_dt=0.004, episode_length=500, Kp=35.0, Kd=0.5, action_repeat=1, action_scale=0.3,
+    soft_joint_pos_limit_factor=0.9, init_from_crouch=0.0, energy_termination_threshold=float("inf"),
+    noise_config=dict(level=1.0, scales=dict(joint_pos=0.01, joint_vel=1.5, gyro=0.2, gravity=0.05, linvel=0.1)),
+    reward_config=dict(scales=dict(height=1.0, orientation=1.0, contact=-0.1, action_rate=0.0, termination=0.0, dof_pos_limits=-0.5,
+                                   torques=0.0, pose=-0.1, stay_still=0.0, energy=0.0, dof_acc=0.0)),
+)
+_HANDSTAND_VARIANTS = {
+    # unwanted-contact geoms, feet geoms of the contact cost, joint ids of the pose cost, desired forward vector, desired height
+    "handstand": (("fl_calf1", "fl_calf2", "fr_calf1", "fr_calf2", "fl_thigh1", "fl_thigh2", "fl_thigh3", "fr_thigh1", "fr_thigh2",
+                   "fr_thigh3", "fl_hip", "fr_hip"), ("RR", "RL"), (6, 7, 8, 9, 10, 11), (0.0, 0.0, -1.0), 0.55),
+    "footstand": (("rl_calf1", "rl_calf2", "rr_calf1", "rr_calf2", "rl_thigh1", "rl_thigh2", "rl_thigh3", "rr_thigh1", "rr_thigh2",
+                   "rr_thigh3", "rl_hip", "rr_hip"), ("FR", "FL"), (0, 1, 2, 3, 4, 5), (0.0, 0.0, 1.0), 0.53),
+}
+
+
+def handstand_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto_reset: bool = False,
+                         variant: str = "handstand") -> Dict[str, np.ndarray]:
+    """`m` must already carry the base.py overrides (go2_apply_overrides).  Field layout: oracle/rsr_oracle.c, "Go2 Handstand"."""
+    if config["action_repeat"] != 1:
+        raise NotImplementedError("action_repeat != 1")
+    unwanted, feet, joint_ids, fwd, z_des = _HANDSTAND_VARIANTS[variant]
+    A = m.arrays
+    n_sub = int(round(config["ctrl_dt"] / config["sim_dt"]))
+    home = A["key_qpos"][m.names["key"]["home"]].astype(np.float32)
+    crouch = A["key_qpos"][m.names["key"]["pre_recovery"]].astype(np.float32)
+    lo, hi = A["jnt_range"][1:, 0], A["jnt_range"][1:, 1]                      # handstand.py:74-78
+    c, r = (lo + hi) / 2, hi - lo
+    f = config["soft_joint_pos_limit_factor"]
+    soft = np.concatenate([c - 0.5 * r * f, c + 0.5 * r * f]).astype(np.float32)
+    ids = np.array([m.id("site", "imu"), m.id("geom", "floor")] + [m.id("geom", g) for g in unwanted] + [m.id("geom", g) for g in feet] +
+                   [m.id("body", "trunk")], dtype=np.int32)
+    nz, rc = config["noise_config"], config["reward_config"]
+    thr = config["energy_termination_threshold"]
+    fl = np.array([config["ctrl_dt"], config["action_scale"], nz["level"], nz["scales"]["joint_pos"], nz["scales"]["joint_vel"],
+                   nz["scales"]["gyro"], nz["scales"]["gravity"], nz["scales"]["linvel"], config["init_from_crouch"],
+                   np.finfo(np.float32).max if not np.isfinite(thr) else thr, z_des, *fwd], dtype=np.float32)
+    flags = (WRAP_EPISODE if episode_length > 0 else 0) | (WRAP_AUTORESET if auto_reset else 0)
+    return dict(
+        env_int=np.array([ENV_GO2_HANDSTAND, n_sub, episode_length, flags, HANDSTAND_OBS_DIM, len(HANDSTAND_METRICS)], dtype=np.int32),
+        env_ids=ids,
+        env_go2f=fl,
+        env_go2i=np.array(joint_ids, dtype=np.int32),
+        env_go2_scales=np.array([rc["scales"][k] for k in HANDSTAND_REWARDS], dtype=np.float32),
+        env_go2_home=np.concatenate([home, crouch]),
+        env_go2_soft=soft,
         env_action_scale=np.zeros(m.nu, np.float32), env_ctrl_lo=A["actuator_ctrlrange"][:, 0].astype(np.float32),
         env_ctrl_hi=A["actuator_ctrlrange"][:, 1].astype(np.float32), env_reset=np.zeros(1, np.float32),
         env_reward=np.zeros(1, np.float32),

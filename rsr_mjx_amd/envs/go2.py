@@ -187,12 +187,53 @@ def domain_randomize(sys, rng: np.ndarray) -> Dict[str, np.ndarray]:
                 dof_armature=arma, actuator_gainprm=gain, actuator_biasprm=bias, dof_damping=damp)
 
 
-_ENVS = {"Go2JoystickFlatTerrain": dict(task="flat_terrain"),       # _src/locomotion/__init__.py:16-26
-         "Go2JoystickRoughTerrain": dict(task="rough_terrain")}
+class Handstand(Joystick):
+    """Go2 Handstand task (reference go2/handstand.py:53-291) on the full-collision-vs-floor model (scene_mjx_flat_terrain.xml ->
+    go2_mjx.xml: 4 foot spheres, 20 capsules, 6 cylinders against the floor plane): 45-dim `state`, 94-dim `privileged_state`,
+    eleven reward terms, termination on a fall, an unwanted contact or the energy threshold."""
+
+    _obs_dim = cfg.HANDSTAND_OBS_DIM
+    _priv_dim = cfg.HANDSTAND_PRIV_OBS_DIM
+    _metrics = cfg.HANDSTAND_METRICS
+    _variant = "handstand"
+
+    def __init__(self, config: Optional[dict] = None, config_overrides: Optional[Dict[str, Any]] = None,
+                 model_path: Optional[str] = None, device: str = "cuda:0"):
+        self._config = cfg._merge(config or cfg.HANDSTAND_DEFAULT_CONFIG, config_overrides or {})
+        if model_path is None:
+            base = CompiledModel.load(os.path.join(_ASSETS, "go2_full.npz"))
+        elif model_path.endswith(".npz"):
+            base = CompiledModel.load(model_path)
+        else:
+            base = compile_mjcf(model_path)
+        self.sys = cfg.go2_apply_overrides(base, self._config)          # go2/base.py:25-31
+        self._device = device
+        self._kwargs: Dict[str, Any] = {}
+        self._n_frames = int(round(self._config["ctrl_dt"] / self._config["sim_dt"]))
+        cfg.handstand_env_fields(self.sys, self._config, variant=self._variant)
+
+    def _fields_fn(self, sys, episode_length=0, auto_reset=False, **_):
+        return cfg.handstand_env_fields(sys, self._config, episode_length, auto_reset, variant=self._variant)
+
+    @property
+    def observation_sizes(self) -> Dict[str, tuple]:
+        return {"state": (self._obs_dim,), "privileged_state": (self._priv_dim,)}
 
 
-def load(env_name: str, config: Optional[dict] = None, config_overrides: Optional[Dict[str, Any]] = None, **kw) -> Joystick:
+class Footstand(Handstand):
+    """reference go2/handstand.py:293-342: the mirrored task (stand on the hind feet)."""
+
+    _variant = "footstand"
+
+
+_ENVS = {"Go2JoystickFlatTerrain": (Joystick, dict(task="flat_terrain")),       # _src/locomotion/__init__.py:16-26
+         "Go2JoystickRoughTerrain": (Joystick, dict(task="rough_terrain")),
+         "Go2Handstand": (Handstand, {}), "Go2Footstand": (Footstand, {})}
+
+
+def load(env_name: str, config: Optional[dict] = None, config_overrides: Optional[Dict[str, Any]] = None, **kw):
     """Counterpart of reference _src/registry.py:24-31."""
     if env_name not in _ENVS:
         raise ValueError(f"Env '{env_name}' not found. Available envs: {sorted(_ENVS)}")
-    return Joystick(config=config, config_overrides=config_overrides, **_ENVS[env_name], **kw)
+    cls, args = _ENVS[env_name]
+    return cls(config=config, config_overrides=config_overrides, **args, **kw)

@@ -30,7 +30,7 @@ JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = range(8)
 INT_EULER, INT_RK4, INT_IMPLICIT, INT_IMPLICITFAST = 0, 1, 2, 3
 # pair kinds understood by the stepper
-PAIR_PLANE_BOX, PAIR_BOX_BOX, PAIR_PLANE_SPHERE, PAIR_HFIELD_SPHERE = 0, 1, 2, 3
+PAIR_PLANE_BOX, PAIR_BOX_BOX, PAIR_PLANE_SPHERE, PAIR_HFIELD_SPHERE, PAIR_PLANE_CAPSULE, PAIR_PLANE_CYLINDER = 0, 1, 2, 3, 4, 5
 
 MJ_MINVAL = 1e-15
 
@@ -651,9 +651,24 @@ class MjcfCompiler:
                 size = np.zeros(3)
                 sv = _vec(g.get("size"), None, default=[0, 0, 0])
                 size[:min(3, sv.size)] = sv[:3]
+                gpos, gquat = _vec(g.get("pos"), 3, default=[0, 0, 0]), self._orient(g)
+                if g.get("fromto") is not None:
+                    # MuJoCo's compiler: the geom sits at the segment's midpoint, its z axis along from - to, and the half length
+                    # is the segment's (capsule / cylinder: size[1]; box / ellipsoid: size[2])
+                    ft = _vec(g.get("fromto"), 6)
+                    vec = ft[:3] - ft[3:]
+                    ln = float(np.linalg.norm(vec))
+                    if gt in (GEOM_CAPSULE, GEOM_CYLINDER):
+                        size[1] = ln / 2
+                    elif gt in (GEOM_BOX, GEOM_ELLIPSOID):
+                        size[2] = ln / 2
+                    else:
+                        raise NotImplementedError(f"fromto on geom type {g.get('type')}")
+                    gpos = 0.5 * (ft[:3] + ft[3:])
+                    gquat = self._orient({"zaxis": " ".join(repr(float(x)) for x in vec)})
                 g_rows["size"].append(size)
-                g_rows["pos"].append(_vec(g.get("pos"), 3, default=[0, 0, 0]))
-                g_rows["quat"].append(self._orient(g))
+                g_rows["pos"].append(gpos)
+                g_rows["quat"].append(gquat)
                 fr = np.array([1.0, 0.005, 0.0001])
                 fv = _vec(g.get("friction"))
                 if fv is not None:
@@ -853,6 +868,10 @@ class MjcfCompiler:
                             kind = PAIR_PLANE_SPHERE
                         elif (ta, tb) == (GEOM_HFIELD, GEOM_SPHERE):
                             kind = PAIR_HFIELD_SPHERE
+                        elif (ta, tb) == (GEOM_PLANE, GEOM_CAPSULE):
+                            kind = PAIR_PLANE_CAPSULE
+                        elif (ta, tb) == (GEOM_PLANE, GEOM_CYLINDER):
+                            kind = PAIR_PLANE_CYLINDER
                         else:
                             raise NotImplementedError(f"collision pair of geom types {ta},{tb}")
                         P["g1"].append(a)

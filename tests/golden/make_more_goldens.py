@@ -1,6 +1,7 @@
-"""Generates tests/golden/{tshape,go2_flat,go2_rough}_n4.npz with the CPU oracle (fp32): small-N versions of BASELINE.json
-configs[2], [3] and [4] (T-shape, Go2 flat, Go2 rough).  Keys split(PRNGKey(0), 4); actions from numpy default_rng(0)
-(T-shape U(-1,1); Go2 N(0, 0.3) clipped); raw wrappers as the bench uses them (episode 1200 / 1000, auto-reset).
+"""Generates tests/golden/{tshape,go2_flat,go2_rough,go2_handstand}_n4.npz with the CPU oracle (fp32): small-N versions of
+BASELINE.json configs[2], [3] and [4] (T-shape, Go2 flat, Go2 rough) and of the Go2 Handstand task.  Keys split(PRNGKey(0), 4);
+actions from numpy default_rng(0) (T-shape U(-1,1); Go2 N(0, 0.3) clipped; Handstand N(0, 0.05): its targets integrate the
+actions); raw wrappers as the bench uses them (episode 1200 / 1000 / 500, auto-reset).
 
 Like cube_n4_200.npz these are regression fixtures of the oracle, NOT reference outputs (the JAX/MJX reference cannot run
 in this pipeline; parity with MJX stays unpinned).  Run: python tests/golden/make_more_goldens.py
@@ -35,11 +36,17 @@ def cases():
         e = go2.load(task)
         f = model_fields(e.sys); f.update(e._fields_fn(e.sys, 1000, True))
         yield name, pack_blob(f), 12, 0.3, ["info_go2", "info_steps", "priv_obs"]
+    e = go2.load("Go2Handstand")
+    f = model_fields(e.sys); f.update(e._fields_fn(e.sys, 500, True))
+    yield "go2_handstand_n4", pack_blob(f), 12, 0.05, ["info_go2", "info_steps", "priv_obs"]
 
 
 def main():
     n, steps = 4, 100
+    only = sys.argv[1:]
     for name, blob, nu, std, info in cases():
+        if only and name not in only:
+            continue
         orc = O.Oracle(blob)
         keys = prng.split(prng.PRNGKey(0), n)
         rng = np.random.default_rng(0)

@@ -184,3 +184,92 @@ def test_hfield_sphere_closest_surface_point(lib64):
     off = np.array([0.5, -0.25, 0.125])
     n1, d1, p1, n1v = _hfield_sphere(lib64, hsize, data, off + Rz @ c, 0.04, hpos=off, hmat=Rz)
     np.testing.assert_allclose([d1, *p1, *n1v], [d0, *(off + Rz @ p0), *(Rz @ n0v)], atol=1e-12)
+
+
+# ---- plane-capsule / plane-cylinder (the Go2 full-collision model of the Handstand task: go2_mjx.xml) ----
+def _surface_samples_capsule(rng, pos, R, radius, halflen, n=60000):
+    """points on a capsule's surface: the cylinder wall and the two end caps"""
+    t = rng.uniform(-halflen, halflen, n); a = rng.uniform(0, 2 * np.pi, n)
+    wall = np.stack([radius * np.cos(a), radius * np.sin(a), t], 1)
+    v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+    caps = v * radius + np.where(v[:, 2:3] > 0, 1.0, -1.0) * np.array([0, 0, halflen])
+    return np.concatenate([wall, caps]) @ R.T + pos
+
+
+def _surface_samples_cylinder(rng, pos, R, radius, halflen, n=60000):
+    t = rng.uniform(-halflen, halflen, n); a = rng.uniform(0, 2 * np.pi, n)
+    wall = np.stack([radius * np.cos(a), radius * np.sin(a), t], 1)
+    rim = np.stack([radius * np.cos(a), radius * np.sin(a), np.where(rng.uniform(size=n) > 0.5, halflen, -halflen)], 1)
+    return np.concatenate([wall, rim]) @ R.T + pos
+
+
+def test_plane_capsule_against_surface_samples(lib64):
+    """Two contacts, the end spheres of the segment: each one's depth is its sphere's, the deeper one is the deepest point of the
+    whole capsule surface, the points lie mid-way between sphere and plane, and the frame's first tangent is the capsule axis projected
+    into the plane."""
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        Rp, Rc = _rand_rot(rng, 0.3), _rand_rot(rng)
+        pp, cp = rng.normal(size=3) * 0.1, rng.normal(size=3) * 0.1
+        radius, halflen = rng.uniform(0.01, 0.05), rng.uniform(0.03, 0.15)
+        out, nrm, frame = np.zeros(8), np.zeros(3), np.zeros(9)
+        n = lib64.oracle_plane_capsule(pp.ctypes.data, np.ascontiguousarray(Rp).ctypes.data, cp.ctypes.data, np.ascontiguousarray(Rc).ctypes.data,
+                                       radius, halflen, out.ctypes.data, nrm.ctypes.data, frame.ctypes.data)
+        assert n == 2
+        nn = Rp[:, 2]
+        np.testing.assert_allclose(nrm, nn, atol=1e-12)
+        pts = _surface_samples_capsule(rng, cp, Rc, radius, halflen)
+        h = (pts - pp) @ nn                                   # signed height of the surface samples above the plane
+        axis = Rc[:, 2]
+        for i, sg in enumerate((1.0, -1.0)):                  # +axis end first
+            end = cp + sg * axis * halflen
+            dist, pos = out[4 * i], out[4 * i + 1:4 * i + 4]
+            assert abs(dist - ((end - pp) @ nn - radius)) < 1e-12
+            np.testing.assert_allclose(pos, end - nn * (radius + 0.5 * dist), atol=1e-12)
+        assert abs(min(out[0], out[4]) - h.min()) < 2e-3 * radius + 1e-6
+        f = frame.reshape(3, 3)
+        np.testing.assert_allclose(f[0], nn, atol=1e-12)
+        b = axis - nn * (nn @ axis)
+        if np.linalg.norm(b) >= 0.5:
+            np.testing.assert_allclose(f[1], b / np.linalg.norm(b), atol=1e-12)
+            np.testing.assert_allclose(f @ f.T, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(f[2], np.cross(f[0], f[1]), atol=1e-12)
+
+
+def test_plane_cylinder_against_surface_samples(lib64):
+    """Three contacts on the rim of the disk facing the plane (or on both disks when the cylinder lies flat): the first is the deepest
+    point of the whole surface, every contact point projects onto a point of the cylinder's surface (pos + n * dist / 2 is ON the
+    surface), and its dist is that surface point's height."""
+    rng = np.random.default_rng(6)
+    flat_seen = 0
+    for trial in range(80):
+        Rp = _rand_rot(rng, 0.3)
+        Rc = _rand_rot(rng)
+        if trial % 4 == 0:                                     # lying flat: axis in the plane
+            nn = Rp[:, 2]
+            ax = np.cross(nn, rng.normal(size=3)); ax /= np.linalg.norm(ax)
+            x = np.cross(ax, nn)
+            Rc = np.stack([x, np.cross(ax, x), ax], 1)
+            flat_seen += 1
+        pp, cp = rng.normal(size=3) * 0.1, rng.normal(size=3) * 0.1
+        radius, halflen = rng.uniform(0.02, 0.06), rng.uniform(0.01, 0.13)
+        out, nrm = np.zeros(12), np.zeros(3)
+        n = lib64.oracle_plane_cylinder(pp.ctypes.data, np.ascontiguousarray(Rp).ctypes.data, cp.ctypes.data, np.ascontiguousarray(Rc).ctypes.data,
+                                        radius, halflen, out.ctypes.data, nrm.ctypes.data)
+        assert n == 3
+        nn = Rp[:, 2]
+        pts = _surface_samples_cylinder(rng, cp, Rc, radius, halflen, n=150000)
+        h = (pts - pp) @ nn
+        assert abs(out[0] - h.min()) < 3e-3 * radius + 1e-6, (trial, out[0], h.min())
+        for i in range(3):
+            dist, pos = out[4 * i], out[4 * i + 1:4 * i + 4]
+            surf = pos + nn * dist * 0.5                       # the surface point the contact stands for
+            loc = Rc.T @ (surf - cp)
+            assert abs(np.hypot(loc[0], loc[1]) - radius) < 1e-9 * 1e3 or np.hypot(loc[0], loc[1]) <= radius + 1e-9, (trial, i)
+            assert abs(abs(loc[2]) - halflen) < 1e-9                                    # on a disk's plane
+            assert abs((surf - pp) @ nn - dist) < 1e-9                                   # dist = that point's height
+        # the two side points are 120 degrees from the deepest one on the same rim (not in the flat case's second point)
+        l0, l2 = Rc.T @ (out[1:4] + nn * out[0] * 0.5 - cp), Rc.T @ (out[9:12] + nn * out[8] * 0.5 - cp)
+        c = (l0[:2] @ l2[:2]) / (np.linalg.norm(l0[:2]) * np.linalg.norm(l2[:2]))
+        assert abs(c + 0.5) < 1e-6, (trial, c)
+    assert flat_seen >= 10

@@ -18,7 +18,11 @@ GNAME = {"priv_obs": "privileged_obs"}
 
 
 def _cases():
-    return [("tshape_n4", None), ("go2_flat_n4", "Go2JoystickFlatTerrain"), ("go2_rough_n4", "Go2JoystickRoughTerrain")]
+    return [("tshape_n4", None), ("go2_flat_n4", "Go2JoystickFlatTerrain"), ("go2_rough_n4", "Go2JoystickRoughTerrain"),
+            ("go2_handstand_n4", "Go2Handstand")]
+
+
+_EPISODE = {"Go2Handstand": 500}
 
 
 def _blob(name, task, tshape_model=None):
@@ -26,7 +30,7 @@ def _blob(name, task, tshape_model=None):
         return make_blob(tshape_model, "tshape", episode_length=1200, auto_reset=True)
     from rsr_mjx_amd.envs import go2
     e = go2.load(task)
-    f = model_fields(e.sys); f.update(e._fields_fn(e.sys, 1000, True))
+    f = model_fields(e.sys); f.update(e._fields_fn(e.sys, _EPISODE.get(task, 1000), True))
     return pack_blob(f)
 
 
@@ -43,7 +47,7 @@ def test_oracle_reproduces_golden(name, task, tshape_model, oracle_mod):
         orc.step(st, g["actions"][t])
         np.testing.assert_array_equal(st["obs"], g["obs"][t], err_msg=f"{name} step {t}")
         np.testing.assert_array_equal(st["reward"], g["reward"][t])
-    assert np.isfinite(g["obs"]).all() and g["done"].sum() == 0
+    assert np.isfinite(g["obs"]).all() and g["done"].sum() == (1 if name == "go2_handstand_n4" else 0)      # (the handstand run holds one termination + auto-reset)
     assert np.abs(np.diff(g["obs"], axis=0)).max() > 1e-3                 # the envs move
 
 
@@ -59,7 +63,7 @@ def test_hip_lands_on_golden(name, task):
         info = ["info_target_base_pos", "info_target_vertical_pos", "info_target_w", "info_new_T_pos", "info_T_pos", "info_xita", "info_steps"]
     else:
         from rsr_mjx_amd.envs import go2
-        env = go2.load(task).batched(n, episode_length=1000, auto_reset=True)
+        env = go2.load(task).batched(n, episode_length=_EPISODE.get(task, 1000), auto_reset=True)
         info = ["info_go2", "info_steps"]
     env.reset(g["keys"])
     torch.cuda.synchronize()
@@ -75,7 +79,7 @@ def test_hip_lands_on_golden(name, task):
         env.step(state, g["actions"][t])
         torch.cuda.synchronize()
         np.testing.assert_array_equal(get("done", g[f"post{t}_done"]), g[f"post{t}_done"])
-        kind = {"tshape_n4": "tshape", "go2_flat_n4": "go2", "go2_rough_n4": "go2rough"}[name]
+        kind = {"tshape_n4": "tshape", "go2_flat_n4": "go2", "go2_rough_n4": "go2rough", "go2_handstand_n4": "handstand"}[name]
         for f in ("obs", "reward", "xpos", "qpos", "qvel"):
             want = g[f"post{t}_{f}"]
             tol = PE.bound(kind, "reset" if t == 0 else "rollout", f)       # per field: 3 x the measured maximum (tests/parity_envelopes.py)
