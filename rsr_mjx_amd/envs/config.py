@@ -242,7 +242,11 @@ _HANDSTAND_VARIANTS = {
 
 def handstand_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto_reset: bool = False,
                          variant: str = "handstand") -> Dict[str, np.ndarray]:
-    """`m` must already carry the base.py overrides (go2_apply_overrides).  Field layout: oracle/rsr_oracle.c, "Go2 Handstand"."""
+    """`m` must already carry the base.py overrides (go2_apply_overrides).
+    env_ids: imu site, floor geom, the twelve unwanted-contact geoms, the two feet geoms of the contact cost, trunk body.
+    env_go2f: ctrl_dt, action_scale, noise level, scales joint_pos / joint_vel / gyro / gravity / linvel, init_from_crouch,
+    energy_termination_threshold, z_des, desired forward vector (3).  env_go2i: joint ids of the pose cost.  env_go2_scales: the eleven
+    reward scales in config order.  env_go2_home: home qpos | pre_recovery qpos.  env_go2_soft: soft lower | soft upper limits."""
     if config["action_repeat"] != 1:
         raise NotImplementedError("action_repeat != 1")
     unwanted, feet, joint_ids, fwd, z_des = _HANDSTAND_VARIANTS[variant]
