@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--no-dr", action="store_true", help="disable domain randomisation")
-    ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2", "go2rough"],
+    ap.add_argument("--workload", default="cube", choices=["cube", "tshape", "go2", "go2rough", "handstand"],
                     help="cube = BASELINE headline (configs[1] family); tshape / go2 / go2rough = configs[2] / [3] / [4] families")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the bounded CPU-oracle sample")
@@ -245,11 +245,11 @@ def main():
     key_env = prng.split(prng.PRNGKey(0), 3)[1]
     lo, hi = shard_range(total, rank, world)
     keys = shard_keys(key_env, total, rank, world)
-    if args.workload in ("go2", "go2rough"):
+    if args.workload in ("go2", "go2rough", "handstand"):
         from rsr_mjx_amd.envs import go2
-        wl_name = "Go2JoystickFlatTerrain" if args.workload == "go2" else "Go2JoystickRoughTerrain"
+        wl_name = {"go2": "Go2JoystickFlatTerrain", "go2rough": "Go2JoystickRoughTerrain", "handstand": "Go2Handstand"}[args.workload]
         envdef = go2.load(wl_name, device=f"cuda:{local_rank}")
-        dr, ep_len, act_std = None, 1000, 0.3
+        dr, ep_len, act_std = None, (500 if args.workload == "handstand" else 1000), 0.3
         args.no_dr = True
     elif args.workload == "tshape":
         from rsr_mjx_amd.envs.airbot import AirbotTShape
@@ -300,7 +300,7 @@ def main():
     timeouts = env.handoff_timeouts()         # outside the timed region: the work queue's sticky error word (0 on a healthy run)
 
     if rank == 0:
-        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536}[args.workload]
+        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536, "handstand": 1788}[args.workload]
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()
@@ -328,8 +328,9 @@ def main():
                 "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
                 "csrc_sha16": sha, "dr_keys": "replicated per GPU (RSR/train.py:212-217)" if args.replicated_dr else "global fan-out sliced per rank",
                 "kernel": {"cube": "rsr::step_kernel<CubeDims, ENV_CUBE>", "tshape": "rsr::step_kernel<TShapeDims, ENV_TSHAPE>",
-                           "go2": "rsr::go2_step_kernel<Go2Dims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>"}[args.workload]
-                          + " (one wavefront per env" + ("" if args.workload.startswith("go2") else "; persistent waves draw (env, substep) work units from a ticket queue") + ")",
+                           "go2": "rsr::go2_step_kernel<Go2Dims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>",
+                           "handstand": "rsr::hs_step_kernel<HandDims>"}[args.workload]
+                          + " (one wavefront per env" + ("" if args.workload.startswith("go2") or args.workload == "handstand" else "; persistent waves draw (env, substep) work units from a ticket queue") + ")",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),
                 "mean_newton_iters_last_substep": stats[0], "mean_linesearch_iters_last_substep": stats[1],
                 "mean_active_contacts": stats[2], "dropped_contacts_mean": stats[3], "handoff_timeouts": timeouts,

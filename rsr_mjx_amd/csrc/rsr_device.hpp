@@ -23,9 +23,9 @@ namespace rsr {
 #define RSR_MAXIMP 0.9999f
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
-enum { PAIR_PLANE_BOX = 0, PAIR_BOX_BOX = 1, PAIR_PLANE_SPHERE = 2, PAIR_HFIELD_SPHERE = 3 };
+enum { PAIR_PLANE_BOX = 0, PAIR_BOX_BOX = 1, PAIR_PLANE_SPHERE = 2, PAIR_HFIELD_SPHERE = 3, PAIR_PLANE_CAPSULE = 4, PAIR_PLANE_CYLINDER = 5 };
 enum { INT_EULER = 0, INT_IMPLICITFAST = 3 };
-enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3 };
+enum { ENV_CUBE = 0, ENV_TSHAPE = 1, ENV_AIRBOT_SF = 2, ENV_GO2 = 3, ENV_GO2_HANDSTAND = 4 };
 
 // ---- device view of the model blob (pointers into one device copy of the blob) ----
 // Pointers of the model view are global-memory pointers, typed as such in device code: a pointer loaded from a struct in memory
@@ -155,8 +155,11 @@ struct StepArgs {
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,
           int NCON_, int OBS_, int NMET_, int NEG_ = 0, int EG0_ = 0, int CONDIM_ = 4, int NINFO_ = 0, int ISO0_ = 0, int ISO1_ = 0, bool DREX_ = false, bool HFIELD_ = false,
-          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false, bool ARROW_ = false, int TREE1_ = 0, int TREE2_ = 0>
+          bool TALIAS_ = false, int NGA_ = NG_, bool TTAIL_ = false, bool ARROW_ = false, int TREE1_ = 0, int TREE2_ = 0, bool CAPS_ = false>
 struct Dims {
+  // plane-capsule / plane-cylinder pairs are compiled in (the Go2 model of the Handstand task); a capsule's contacts carry the
+  // first tangent of their frame (it follows the capsule axis) from the narrow phase to the constraint rows
+  static constexpr bool CAPS = CAPS_;
   // LDS diet of the single-iteration models (Go2: one Hessian per substep, explicit Euler): the transpose / exchange scratch T
   // has no storage of its own -- before the solve it is the dead part of phase A (cinert .. cfrcsum), from the Hessian on it
   // is the mass matrix's storage (M is read for the last time when the Hessian blocks are formed) -- and geom frames /
@@ -468,6 +471,8 @@ struct Smem {
   }
   // contacts (active only)
   float cdist[C::NCON], cpos[C::NCON * 3], cnrm[C::NCON * 3];
+  float ctan[C::CAPS ? C::NCON * 3 : 0];               // Dims::CAPS: first tangent of the contact's frame, zero = the default frame of the normal
+                                                       // (no storage in the other models: their LDS images keep their size)
   int cpair[C::NCON];
   int ncon, ncon_drop, nlim_act;
   int trees_joined;          // Dims::ROWTREE: a contact pair of this substep joins two kinematic trees (the Hessian needs the coupled layout)
@@ -1241,7 +1246,7 @@ __device__ __forceinline__ void manifold_points(const float* x, const float* y, 
   idx[0] = a; idx[1] = b; idx[2] = c; idx[3] = dd;
 }
 
-struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; };
+struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; V3 t; };      // t: first tangent of the frame (Dims::CAPS), zero = default
 // append without a runtime array index (a runtime index would put the whole struct in scratch memory)
 __device__ __forceinline__ void cpts_push(CPts& o, float dist, V3 pos) {
 #pragma unroll
@@ -1511,7 +1516,7 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
 
 template <class C>
 __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>& s, int lane PROF_ARG) {
-  CPts pts; pts.cnt = 0;
+  CPts pts; pts.cnt = 0; pts.t = v3(0, 0, 0);
   ClipJob job; job.kind = 0;
   float incl = 0.0f;
   const int lr = lrec_lane(lane);
@@ -1533,6 +1538,55 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
       float r = size2.x;
       float dist = dot(p2 - p1, n) - r;
       pts.n = n; pts.dist[0] = dist; pts.pos[0] = p2 - n * (r + 0.5f * dist); pts.cnt = 1;
+    }
+    if constexpr (C::CAPS) {
+      // mujoco-mjx 3.2.x collision_primitive.plane_capsule / plane_cylinder, as restated in the oracle (same operations in the same order)
+      if (kind == PAIR_PLANE_CAPSULE) {
+        const V3 n = col(R1.m, 2), axis = col(R2.m, 2);
+        const float na = dot(n, axis);
+        V3 b = axis - n * na;
+        const float bn = sqrtf(dot(b, b));
+        if (bn < 0.5f) b = (n.y > -0.5f && n.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
+        else b = v3(b.x / bn, b.y / bn, b.z / bn);
+        const float r = size2.x, hl = size2.y;
+        pts.n = n; pts.t = b; pts.cnt = 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float sg = i == 0 ? 1.0f : -1.0f;
+          const V3 ctr = p2 + (axis * sg) * hl;
+          const float dist = dot(ctr - p1, n) - r;
+          pts.dist[i] = dist; pts.pos[i] = ctr - n * (r + 0.5f * dist);
+        }
+      } else if (kind == PAIR_PLANE_CYLINDER) {
+        const V3 n = col(R1.m, 2);
+        V3 axis = col(R2.m, 2);
+        float prjaxis = dot(n, axis);
+        const float sign = prjaxis < 0.0f ? 1.0f : -1.0f;
+        axis = axis * sign; prjaxis *= sign;
+        const float r = size2.x, hl = size2.y;
+        const float dist0 = dot(p2 - p1, n);
+        V3 vec = axis * prjaxis - n;
+        const float len = sqrtf(dot(vec, vec));
+        if (len < 1e-12f) vec = col(R2.m, 0) * r;
+        else vec = v3(vec.x / len * r, vec.y / len * r, vec.z / len * r);
+        const float prjvec = dot(vec, n);
+        axis = axis * hl; prjaxis *= hl;
+        const float prjvec1 = -prjvec * 0.5f;
+        V3 vec1 = cross(vec, axis);
+        const float l1 = sqrtf(dot(vec1, vec1));
+        const float s3 = 1.7320508075688772f;
+        vec1 = v3((l1 > 0.0f ? vec1.x / l1 : 0.0f) * r * s3 * 0.5f, (l1 > 0.0f ? vec1.y / l1 : 0.0f) * r * s3 * 0.5f, (l1 > 0.0f ? vec1.z / l1 : 0.0f) * r * s3 * 0.5f);
+        const float d1 = dist0 + prjaxis + prjvec, d2 = dist0 + prjaxis + prjvec1;
+        pts.n = n; pts.cnt = 3;
+        pts.dist[0] = d1; pts.dist[1] = d2; pts.dist[2] = d2;
+        pts.pos[0] = p2 + axis + vec - n * d1 * 0.5f;
+        pts.pos[1] = p2 + axis + vec1 + vec * -0.5f - n * d2 * 0.5f;
+        pts.pos[2] = p2 + axis - vec1 + vec * -0.5f - n * d2 * 0.5f;
+        if (fabsf(prjaxis) < 1e-3f) {          // lying parallel to the plane: the second point moves to the other disk
+          const float d3 = dist0 - prjaxis + prjvec;
+          pts.dist[1] = d3; pts.pos[1] = p2 + vec - axis - n * d3 * 0.5f;
+        }
+      }
     }
     if constexpr (C::HFIELD) {
       if (kind == PAIR_HFIELD_SPHERE) {
@@ -1640,6 +1694,7 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
     if (!(i < pts.cnt && pts.dist[i] - incl < 0.0f)) continue;
     if (w < C::NCON) {
       s.cdist[w] = pts.dist[i]; st3(&s.cpos[3 * w], pts.pos[i]); st3(&s.cnrm[3 * w], pts.n); s.cpair[w] = lane;
+      if constexpr (C::CAPS) st3(&s.ctan[3 * w], pts.t);
     }
     w++;
   }
@@ -1877,6 +1932,10 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
   if (lane < ncon) {
     V3 nn, t1, t2;
     make_frame(ld3(&s.cnrm[3 * lane]), nn, t1, t2);
+    if constexpr (C::CAPS) {           // a capsule's frame: (n, b, n x b) with b along the capsule axis, n as the narrow phase gave it
+      const V3 b = ld3(&s.ctan[3 * lane]);
+      if (b.x != 0.0f || b.y != 0.0f || b.z != 0.0f) { nn = ld3(&s.cnrm[3 * lane]); t1 = b; t2 = cross(nn, b); }
+    }
     st3(&s.cnrm[3 * lane], nn); st3(&s.rw[6 * lane], t1); st3(&s.rw[6 * lane + 3], t2);
   }
   if constexpr (C::ROWTREE) {

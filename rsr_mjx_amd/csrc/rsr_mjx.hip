@@ -25,6 +25,11 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_N
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
                      /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true, /*ARROW*/ true>;
+// Unitree Go2 with every collision geom against the floor (go2_mjx.xml + scene_mjx_flat_terrain.xml, the Handstand / Footstand tasks): 44 geoms,
+// 30 plane pairs of condim 3 (4 spheres, 20 capsules, 6 cylinders: up to 62 contact points, 12 kept active per env -- a state with
+// more is a fall, which ends the episode in the same step)
+using HandDims = Dims<19, 18, 12, 14, 13, 44, 6, 30, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 12, /*OBS*/ 45, /*NMET*/ 11, 0, 0, /*CONDIM*/ 3,
+                      /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ false, /*TALIAS*/ false, /*NGA*/ 44, /*TTAIL*/ true, /*ARROW*/ true, 0, 0, /*CAPS*/ true>;
 using TShapeDims = Dims<15, 14, 5, 14, 9, 25, 3, 60, 1, 8, 8, /*NCON*/ 32, /*OBS*/ 16, /*NMET*/ 5, /*NEG*/ 4, /*EG0*/ 5, /*CONDIM*/ 4, 0, 0, 0, false, false, false,
                         /*NGA*/ 25, false, false, /*TREE1, TREE2: arm | T block*/ 8, 14>;
 
@@ -1191,13 +1196,325 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 #endif
 }
 
+
+// ================================================================ Go2 Handstand / Footstand (go2/handstand.py)
+// env_ids: 0 imu site, 1 floor geom, 2..13 the twelve unwanted-contact geoms, 14..15 the feet geoms of the contact cost, 16 trunk body.
+// env_go2f: ctrl_dt, action_scale, noise level, scales joint_pos / joint_vel / gyro / gravity / linvel, init_from_crouch,
+// energy_termination_threshold, z_des, desired forward vector.  env_go2i: joint ids of the pose cost.  env_go2_home: home | pre_recovery
+// qpos.  env_go2_soft: soft lower | upper limits.  info block: step at 0, last_act at 4..15, rng at G2_RNG.
+enum { HS_STEP = 0, HS_LAST_ACT = 4, HS_PRIV = 94 };
+enum { HM_HEIGHT = 0, HM_ORIENT, HM_CONTACT, HM_ACTION_RATE, HM_TERM, HM_DOF_LIMITS, HM_TORQUES, HM_POSE, HM_STAY_STILL, HM_ENERGY, HM_DOF_ACC, HM_COUNT };
+
+// handstand.py:196-245: the 45-dim "state" into obs_lds; five splits of info.rng, draws in the reference's order (gyro, gravity, joint
+// angles, joint velocities, linvel)
+template <class C>
+__device__ __forceinline__ void hs_obs(const DModel& m, Smem<C>& s, const G2Sens& sn, float* obs_lds, uint32_t* bits, int lane) {
+#pragma clang fp contract(off)
+  const float* F = m.env_go2f;
+  uint32_t rng0 = __float_as_uint(s.ginfo[G2_RNG]), rng1 = __float_as_uint(s.ginfo[G2_RNG + 1]);
+  rng0 = (uint32_t)uniform_i((int)rng0); rng1 = (uint32_t)uniform_i((int)rng1);
+  const float level = F[2];
+  const float home_l = m.env_go2_home[7 + (lane < 12 ? lane : 0)];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    uint32_t k2[2][2];
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    const int n = (d == 2 || d == 3) ? 12 : 3;
+    const float u = tf_uniform(k2[1][0], k2[1][1], n, 0.0f, 1.0f, bits, lane);
+    if (lane < n) {
+      float src, scale; int dst;
+      if (d == 0) { src = pick3(sn.gyro, lane); scale = F[5]; dst = 3 + lane; }
+      else if (d == 1) { src = pick3(sn.gravity, lane); scale = F[6]; dst = 6 + lane; }
+      else if (d == 2) { src = s.qpos[7 + lane]; scale = F[3]; dst = 9 + lane; }
+      else if (d == 3) { src = s.qvel[6 + lane]; scale = F[4]; dst = 21 + lane; }
+      else { src = pick3(sn.linvel, lane); scale = F[7]; dst = lane; }
+      float a = 2.0f * u; float b = a - 1.0f; float c = b * level; float e = c * scale;
+      float val = src + e;
+      if (d == 2) val = val - home_l;
+      obs_lds[dst] = val;
+    }
+  }
+  if (lane < 12) obs_lds[33 + lane] = s.ginfo[HS_LAST_ACT + lane];
+  if (lane == 0) { s.ginfo[G2_RNG] = __uint_as_float(rng0); s.ginfo[G2_RNG + 1] = __uint_as_float(rng1); }
+  WSYNC();
+}
+
+// handstand.py:246-259: element t of obs["privileged_state"] (94)
+template <class C>
+__device__ __forceinline__ float hs_priv_elem(const DModel& m, const Smem<C>& s, const G2Sens& sn, const float* obs_lds, int t) {
+  if (t < 45) return obs_lds[t];
+  t -= 45;
+  if (t < 3) return pick3(sn.gyro, t);
+  if (t < 6) return pick3(sn.accel, t - 3);
+  if (t < 9) return pick3(sn.linvel, t - 6);
+  if (t < 12) return pick3(sn.gang, t - 9);
+  if (t < 24) return s.qpos[7 + t - 12];
+  if (t < 36) return s.qvel[6 + t - 24];
+  if (t < 48) return s.aforce[t - 36];
+  if (t == 48) return s.spos[3 * m.env_ids[0] + 2];
+  return 0.0f;
+}
+
+// handstand.py:119-160 + wrappers
+template <class C>
+__global__ __launch_bounds__(64) void hs_reset_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
+  const Hot hot = make_hot(m);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const float* F = m.env_go2f;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.scratch_b());
+  float* obs_lds = s.scratch_b() + 64;
+  load_overrides<C>(m, s, a, e, lane);
+  for (int t = lane; t < C::NINFO; t += 64) s.ginfo[t] = 0.0f;
+  uint32_t rng0 = a.keys[2 * e], rng1 = a.keys[2 * e + 1];
+  uint32_t k2[2][2];
+  tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+  const float ub = rdlane(tf_uniform(k2[1][0], k2[1][1], 1, 0.0f, 1.0f, bits, lane), 0);
+  const bool crouch = ub < F[8];                                       // jax.random.bernoulli(key, p)
+  const float q_init = m.env_go2_home[(crouch ? C::NQ : 0) + (lane < C::NQ ? lane : 0)];
+  if (lane < C::NQ) s.qpos[lane] = q_init;
+  if (lane < C::NV) s.qvel[lane] = 0.0f;
+  WSYNC();
+  {
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float dxy = tf_uniform(k2[1][0], k2[1][1], 2, -0.5f, 0.5f, bits, lane);
+    if (lane < 2) s.qpos[lane] = q_init + dxy;
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float yaw = rdlane(tf_uniform(k2[1][0], k2[1][1], 1, -3.14f, 3.14f, bits, lane), 0);
+    WSYNC();
+    if (lane == 0) {
+#pragma clang fp contract(off)
+      float sn = sinf(yaw * 0.5f), cs = cosf(yaw * 0.5f);
+      Q4 q = ld4(&s.qpos[3]), r = Q4{cs, 0.0f * sn, 0.0f * sn, 1.0f * sn};
+      Q4 o;
+      o.w = q.w * r.w - q.x * r.x - q.y * r.y - q.z * r.z;
+      o.x = q.w * r.x + q.x * r.w + q.y * r.z - q.z * r.y;
+      o.y = q.w * r.y - q.x * r.z + q.y * r.w + q.z * r.x;
+      o.z = q.w * r.z + q.x * r.y - q.y * r.x + q.z * r.w;
+      st4(&s.qpos[3], o);
+    }
+    tf_split<2>(rng0, rng1, bits, lane, k2); rng0 = k2[0][0]; rng1 = k2[0][1];
+    float v6 = tf_uniform(k2[1][0], k2[1][1], 6, -0.5f, 0.5f, bits, lane);
+    if (lane < 6 && !crouch) s.qvel[lane] = v6;
+  }
+  WSYNC();
+  if (lane < C::NU) s.ctrl[lane] = s.qpos[7 + lane];          // mjx_env.init(..., ctrl = qpos[7:])
+  if (lane == 0) {
+    s.xfrc_body = 0; s.acc_body = m.site_bodyid[m.env_ids[0]]; s.xfrc[0] = s.xfrc[1] = s.xfrc[2] = 0.0f;
+    s.ginfo[G2_RNG] = __uint_as_float(rng0); s.ginfo[G2_RNG + 1] = __uint_as_float(rng1);
+  }
+  WSYNC();
+  float Mrow[C::NV], warm = 0.0f;
+  FwdOut<C> f;
+  PROF_DECL
+  forward<C>(m, hot, s, lane, Mrow, warm, f, a.debug ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr PROF_PASS);
+  WSYNC();
+  G2Sens sn;
+  go2_sensors<C>(m, s, sn);
+  go2_accelerometer<C>(m, s, lane, f.qacc, sn);
+  hs_obs<C>(m, s, sn, obs_lds, bits, lane);
+  for (int t = lane; t < GO2_PRIV; t += 64) { float v = hs_priv_elem<C>(m, s, sn, obs_lds, t); rec[L.priv_obs + t] = v; rec[L.f_priv_obs + t] = v; }
+  store_pipeline<C>(s, rec, L, lane, warm, 0.0f);
+  for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];
+  for (int t = lane; t < C::OBS; t += 64) { rec[L.obs + t] = obs_lds[t]; rec[L.f_obs + t] = obs_lds[t]; }
+  if (lane == 0) {
+    rec[L.reward] = 0.0f; rec[L.done] = 0.0f;
+    for (int i = 0; i < C::NMET; ++i) rec[L.metrics + i] = 0.0f;
+    rec[L.steps] = 0.0f; rec[L.truncation] = 0.0f; rec[L.episode_done] = 0.0f;
+    for (int i = 0; i < 2 + C::NMET; ++i) rec[L.episode_metrics + i] = 0.0f;
+    int* st = reinterpret_cast<int*>(rec + L.stats);
+    st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+    rec[L.f_time] = 0.0f;
+  }
+  for (int t = lane; t < C::NQ; t += 64) rec[L.f_qpos + t] = s.qpos[t];
+  if (lane < C::NV) { rec[L.f_qvel + lane] = s.qvel[lane]; rec[L.f_warm + lane] = warm; }
+  if (lane < C::NU) rec[L.f_ctrl + lane] = s.ctrl[lane];
+  for (int t = lane; t < C::NB * 3; t += 64) rec[L.f_xpos + t] = s.xpos[t];
+  for (int t = lane; t < C::NS * 3; t += 64) rec[L.f_site_xpos + t] = s.spos[t];
+}
+
+// handstand.py:161-195 with the rewards :264-342, + wrappers
+template <class C>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
+  const DModel& m = *mp;
+  const Hot hot = make_hot(m);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem<C>& s = *reinterpret_cast<Smem<C>*>(smem_raw);
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= a.n) return;
+  float* rec = a.state + (size_t)e * L.rec;
+  const bool wrap_episode = m.wrap_flags & 1, wrap_autoreset = (m.wrap_flags & 2) != 0;
+  const float* F = m.env_go2f;
+  const float dt = F[0];
+  uint32_t* bits = reinterpret_cast<uint32_t*>(s.scratch_b());
+  float* obs_lds = s.scratch_b() + 64;
+  float* rwl = s.scratch_b() + 128;                                   // scaled reward terms staged for the metrics write
+  float* qacc_lds = s.scratch_b() + 160;                              // qacc of the last forward pass, for the dof_acc term
+  PROF_DECL
+  for (int t = lane; t < C::NQ; t += 64) s.qpos[t] = rec[L.qpos + t];
+  float warm = 0.0f;
+  if (lane < C::NV) { s.qvel[lane] = rec[L.qvel + lane]; warm = rec[L.warm + lane]; }
+  float time = rec[L.time];
+  load_overrides<C>(m, s, a, e, lane);
+  for (int t = lane; t < C::NINFO; t += 64) s.ginfo[t] = rec[L.go2_info + t];
+  const float done_prev = rec[L.done];
+  float steps = rec[L.steps];
+  if (wrap_autoreset && done_prev != 0.0f) steps = 0.0f;
+  const float act_in = lane < C::NU ? a.action[(size_t)e * C::NU + lane] : 0.0f;
+  if (lane < C::NU) {
+#pragma clang fp contract(off)
+    float sc = act_in * F[1];
+    s.ctrl[lane] = rec[L.ctrl + lane] + sc;                          // motor targets = state.data.ctrl + action * action_scale (:162)
+  }
+  if (lane == 0) { s.acc_body = m.site_bodyid[m.env_ids[0]]; s.xfrc_body = 0; s.xfrc[0] = s.xfrc[1] = s.xfrc[2] = 0.0f; }
+  WSYNC();
+  float Mrow[C::NV];
+  FwdOut<C> f;
+  for (int fr = 0; fr < m.n_frames; ++fr) {
+#if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
+    float* dbg = nullptr;
+#else
+    float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
+#endif
+    const int lane_s = lrec_lane(lane);
+    forward<C>(m, hot, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
+    integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
+    time += hot.timestep;
+  }
+  // which pairs the termination / contact cost look at (pairs are static): 1 = an unwanted-contact geom, 2 = a foot of the contact cost
+  int pair_class = 0;
+  if (lane < C::NP) {
+    const int g2 = m.pair_geom2[lane];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) if (g2 == m.env_ids[2 + k]) pair_class = 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) if (g2 == m.env_ids[14 + k]) pair_class = 2;
+  }
+  const float prev_done = wrap_episode ? rec[L.episode_done] : 0.0f;
+  const float em_old = (wrap_episode && lane < C::NMET + 2) ? rec[L.episode_metrics + lane] : 0.0f;
+  G2Sens sn;
+  go2_sensors<C>(m, s, sn);
+  go2_accelerometer<C>(m, s, lane, f.qacc, sn);
+  bool unwanted, feet;
+  {
+    const int nc = s.ncon, ci = lane < nc ? lane : 0;
+    const int cp = s.cpair[ci]; const float cd = s.cdist[ci];
+    const int cls = __shfl(pair_class, cp & 63);
+    const int mine = (lane < nc && cd < 0.0f) ? cls : 0;
+    unwanted = __ballot(mine == 1) != 0ull; feet = __ballot(mine == 2) != 0ull;
+  }
+  if (lane < C::NV) qacc_lds[lane] = f.qacc;
+  WSYNC();
+  hs_obs<C>(m, s, sn, obs_lds, bits, lane);
+  float priv[2];
+  priv[0] = hs_priv_elem<C>(m, s, sn, obs_lds, lane);
+  priv[1] = hs_priv_elem<C>(m, s, sn, obs_lds, lane + 64 < GO2_PRIV ? lane + 64 : GO2_PRIV - 1);
+  float reward = 0.0f, done = 0.0f;
+  if (lane == 0) {
+#pragma clang fp contract(off)
+    const float* SC = m.env_go2_scales; const float* home = m.env_go2_home; const float* soft = m.env_go2_soft;
+    const int imu = m.env_ids[0];
+    const float torso_height = s.spos[3 * imu + 2];
+    float energy = 0.0f;
+    for (int i = 0; i < 12; ++i) energy += fabsf(s.aforce[i]) * fabsf(s.qvel[6 + i]);
+    done = (sn.up[2] < -0.25f || unwanted || energy > F[9]) ? 1.0f : 0.0f;
+    float rw[HM_COUNT];
+    {
+      float h = torso_height < F[10] ? torso_height : F[10];
+      float err = F[10] - h;
+      rw[HM_HEIGHT] = expf(-err / 1.0f);
+      const float* R = &s.smat[9 * imu];
+      float c0 = R[0] * F[11]; float c1 = R[3] * F[12]; float c2 = R[6] * F[13];
+      float cd = c0 + c1; float cos_dist = cd + c2;
+      float nrm = 0.5f * cos_dist; float nr = nrm + 0.5f;
+      rw[HM_ORIENT] = nr * nr;
+      rw[HM_CONTACT] = feet ? 1.0f : 0.0f;
+      float ar = 0.0f, tq = 0.0f, lim = 0.0f, dacc = 0.0f, pose = 0.0f, en = 0.0f;
+      for (int i = 0; i < 12; ++i) {
+        float da = a.action[(size_t)e * C::NU + i] - s.ginfo[HS_LAST_ACT + i]; ar += da * da;
+        float t = s.aforce[i]; tq += t * t;
+        float q = s.qpos[7 + i];
+        float lo_ = q - soft[i]; float hi_ = q - soft[12 + i];
+        lim += -(lo_ < 0.0f ? lo_ : 0.0f) + (hi_ > 0.0f ? hi_ : 0.0f);
+        float qa = qacc_lds[6 + i]; dacc += qa * qa;
+        en += fabsf(s.qvel[6 + i]) * fabsf(t);
+      }
+      for (int k = 0; k < 6; ++k) { const int j = m.env_go2i[k]; float dq = s.qpos[7 + j] - home[7 + j]; pose += dq * dq; }
+      rw[HM_ACTION_RATE] = ar; rw[HM_TORQUES] = tq; rw[HM_TERM] = done; rw[HM_DOF_LIMITS] = lim; rw[HM_DOF_ACC] = dacc; rw[HM_POSE] = pose;
+      float ss = s.qvel[0] * s.qvel[0] + s.qvel[1] * s.qvel[1];
+      rw[HM_STAY_STILL] = ss + s.qvel[5] * s.qvel[5];
+      rw[HM_ENERGY] = en;
+    }
+    for (int k = 0; k < HM_COUNT; ++k) rwl[k] = rw[k] * SC[k];
+    const int order[HM_COUNT] = {HM_HEIGHT, HM_ORIENT, HM_CONTACT, HM_ACTION_RATE, HM_TORQUES, HM_TERM, HM_DOF_LIMITS, HM_DOF_ACC, HM_POSE,
+                                 HM_STAY_STILL, HM_ENERGY};
+    float total = 0.0f;
+    for (int k = 0; k < HM_COUNT; ++k) total = total + rwl[order[k]];
+    reward = clampf(total * dt, 0.0f, 10000.0f);
+  }
+  reward = rdlane(reward, 0); done = rdlane(done, 0);
+  WSYNC();
+  if (lane < C::NU) s.ginfo[HS_LAST_ACT + lane] = act_in;
+  if (lane == 0) s.ginfo[HS_STEP] += 1.0f;
+  WSYNC();
+  {
+    bool over = false;
+    float trunc = 0.0f;
+    if (wrap_episode) {
+      steps += 1.0f;
+      over = steps >= (float)m.episode_length;
+      trunc = over ? 1.0f - done : 0.0f;
+    }
+    if (lane < C::NMET) rec[L.metrics + lane] = rwl[lane];
+    if (wrap_episode && lane < C::NMET + 2) {
+      float* em = rec + L.episode_metrics;
+      const float add = lane == 0 ? reward : (lane == 1 ? 1.0f : rwl[lane >= 2 ? lane - 2 : 0]);
+      em[lane] = prev_done != 0.0f ? 0.0f : em_old + add;
+    }
+    if (over) done = 1.0f;
+    if (lane == 0) {
+      rec[L.reward] = reward;
+      if (wrap_episode) { rec[L.truncation] = trunc; rec[L.episode_done] = done; }
+      rec[L.steps] = steps;
+      rec[L.done] = done;
+      int* st = reinterpret_cast<int*>(rec + L.stats);
+      st[0] = f.st.niter; st[1] = f.st.ls_total; st[2] = s.ncon; st[3] = s.ncon_drop;
+    }
+  }
+  WSYNC();
+  for (int t = lane; t < C::NINFO; t += 64) rec[L.go2_info + t] = s.ginfo[t];       // info is never reset by AutoReset
+  if (wrap_autoreset && done != 0.0f) {
+    for (int t = lane; t < L.persist_end; t += 64) rec[t] = rec[L.f_qpos + t];
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = rec[L.f_obs + t];
+    for (int t = lane; t < GO2_PRIV; t += 64) rec[L.priv_obs + t] = rec[L.f_priv_obs + t];
+  } else {
+    store_pipeline<C>(s, rec, L, lane, warm, time);
+    for (int t = lane; t < C::OBS; t += 64) rec[L.obs + t] = obs_lds[t];
+    rec[L.priv_obs + lane] = priv[0];
+    if (lane + 64 < GO2_PRIV) rec[L.priv_obs + lane + 64] = priv[1];
+  }
+}
+
 // ---------------------------------------------------------------- launchers of the Go2 kernels
 // The Go2 kernels are built as a translation unit of their own (this file with -DRSR_TU_GO2 -fno-slp-vectorize, see
 // rsr_mjx_amd/build.py): the SLP vectoriser's packed-fp32 pairing costs them ~3% while it gains the Airbot kernels ~1%.
 // Kernel templates are instantiated where they are launched, so each unit compiles only its own kernels.
 void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 #ifdef RSR_TU_GO2
+void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
+  hipLaunchKernelGGL((hs_reset_kernel<HandDims>), dim3(n), dim3(64), sizeof(Smem<HandDims>), st, dm, L, a);
+}
+void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
+  hipLaunchKernelGGL((hs_step_kernel<HandDims>), dim3(n), dim3(64), sizeof(Smem<HandDims>), st, dm, L, a);
+}
 void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
   hipLaunchKernelGGL((go2_reset_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
 }
@@ -1295,8 +1612,9 @@ static Layout make_layout(const rsr_dims& d) {
   L.target_pos = take(3); L.new_cube_pos = take(2); L.site_pos = take(3); L.cube_pos = take(3); L.last_action = take(1);
   L.target_base_pos = take(3); L.target_vertical_pos = take(3); L.target_w = take(1); L.new_T_pos = take(2);
   L.T_pos = take(3); L.xita = take(1);
-  L.go2_info = take(d.env_kind == rsr::ENV_GO2 ? 144 : 0);
-  L.priv_obs = take(d.env_kind == rsr::ENV_GO2 ? 123 : 0); L.f_priv_obs = take(d.env_kind == rsr::ENV_GO2 ? 123 : 0);
+  const bool go2_family = d.env_kind == rsr::ENV_GO2 || d.env_kind == rsr::ENV_GO2_HANDSTAND;
+  L.go2_info = take(go2_family ? 144 : 0);
+  L.priv_obs = take(go2_family ? 123 : 0); L.f_priv_obs = take(go2_family ? 123 : 0);
   L.steps = take(1); L.truncation = take(1); L.episode_done = take(1); L.episode_metrics = take(2 + d.nmetrics);
   L.stats = take(4);
   L.rec = (o + 15) & ~15;
@@ -1350,13 +1668,15 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
            d.obs_dim == C::OBS && d.nmetrics == C::NMET;
   };
   bool ok = ((d.env_kind == rsr::ENV_CUBE || d.env_kind == rsr::ENV_AIRBOT_SF) && fits(rsr::CubeDims{})) ||
-            (d.env_kind == rsr::ENV_TSHAPE && fits(rsr::TShapeDims{})) || (d.env_kind == rsr::ENV_GO2 && fits(rsr::Go2Dims{}));
-  const int want_condim = d.env_kind == rsr::ENV_GO2 ? 3 : 4;
-  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape, Go2 joystick flat)"); }
+            (d.env_kind == rsr::ENV_TSHAPE && fits(rsr::TShapeDims{})) || (d.env_kind == rsr::ENV_GO2 && fits(rsr::Go2Dims{})) ||
+            (d.env_kind == rsr::ENV_GO2_HANDSTAND && fits(rsr::HandDims{}));
+  const bool go2_family = d.env_kind == rsr::ENV_GO2 || d.env_kind == rsr::ENV_GO2_HANDSTAND;
+  const int want_condim = go2_family ? 3 : 4;
+  if (!ok) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: model dims / env kind have no compiled kernel (built: Airbot cube, Airbot sf, Airbot T-shape, Go2 joystick, Go2 handstand / footstand)"); }
   if (c2[3] > 1) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: bodies with more than one joint are not built"); }
   {  // geom slots: as many as the kernel's LDS image keeps, each a geom id, every pair geom among them (model.py: geom_slots)
     int ns = 0, np1 = 0; const int* gs = static_cast<const int*>(m->find("geom_slot_ids", &ns));
-    const int want = d.env_kind == rsr::ENV_GO2 ? rsr::Go2Dims::NGA : (d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::NGA : rsr::CubeDims::NGA);
+    const int want = d.env_kind == rsr::ENV_GO2 ? rsr::Go2Dims::NGA : (d.env_kind == rsr::ENV_GO2_HANDSTAND ? rsr::HandDims::NGA : (d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::NGA : rsr::CubeDims::NGA));
     bool okg = gs && ns == want;
     for (int i = 0; okg && i < ns; ++i) okg = gs[i] >= 0 && gs[i] < d.ngeom && (want != d.ngeom || gs[i] == i);
     const int* pg1 = static_cast<const int*>(m->find("pair_geom1", &np1)); const int* pg2 = static_cast<const int*>(m->find("pair_geom2"));
@@ -1367,7 +1687,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
     }
     if (!okg) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: geom_slot_ids do not match the kernel's geom slots (Dims::NGA) or miss a pair geom"); }
   }
-  if (d.env_kind != rsr::ENV_GO2) {
+  if (!go2_family) {
     // the Airbot kernels factor one kinematic tree per DPP row (Dims::ROWTREE): dof ranges [0, TREE1), [TREE1, TREE2), [TREE2, nv)
     // must be separate trees -- no body chain and no equality constraint may straddle them
     const int t1 = d.env_kind == rsr::ENV_TSHAPE ? rsr::TShapeDims::TREE1 : rsr::CubeDims::TREE1;
@@ -1388,7 +1708,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
     }
     if (!okt) { delete m; return fail(RSR_ERR_UNSUPPORTED, "rsr_model_create: the Airbot kernels need the arm and the free bodies as separate kinematic trees over fixed dof ranges"); }
   }
-  if (d.env_kind == rsr::ENV_GO2 && rsr::Go2Dims::ARROW) {
+  if (go2_family && rsr::Go2Dims::ARROW) {
     // the Go2 kernels factor M and H in block-arrow form (Dims::ARROW): dofs 0..5 are the trunk, every further group of three dofs
     // is a leg, and no body chain and no contact pair may touch two legs
     using G = rsr::Go2Dims;
@@ -1453,6 +1773,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
     }
   }
   if (d.env_kind == rsr::ENV_GO2) { using C = rsr::Go2Dims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
+  else if (d.env_kind == rsr::ENV_GO2_HANDSTAND) { using C = rsr::HandDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else if (d.env_kind == rsr::ENV_TSHAPE) { using C = rsr::TShapeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   else { using C = rsr::CubeDims; d.ncon_max = C::NCON; d.nefc_max = C::NEFC; d.lds_bytes = (int32_t)sizeof(rsr::Smem<C>); }
   m->layout = make_layout(d);
@@ -1492,7 +1813,7 @@ static int fill_dmodel(const rsr_model* m, const char* dbase, DModel& dm) {
   { int nrec = 0; m->find("lane_rec", &nrec); if (nrec != rsr::LQ_COUNT * 64 * 4) return fail(RSR_ERR_ARG, "blob field lane_rec has the wrong size (model.py lane_records vs enum LaneQuad)"); }
   P(float, hfield_size) P(float, hfield_data) P(int, hfield_nrow) P(int, hfield_ncol)
   P(int, env_ids) P(float, env_action_scale) P(float, env_ctrl_lo) P(float, env_ctrl_hi) P(float, env_reset) P(float, env_reward)
-  if (dm.env_kind == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2) {
+  if (static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2 || static_cast<const int*>(m->find("env_int"))[0] == rsr::ENV_GO2_HANDSTAND) {
     P(float, env_go2f) P(float, env_go2_scales) P(float, env_go2_home) P(float, env_go2_soft) P(int, env_go2i)
   } else { dm.env_go2f = dm.env_go2_scales = dm.env_go2_home = dm.env_go2_soft = nullptr; dm.env_go2i = nullptr; }
 #undef P
@@ -1546,7 +1867,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { release(); return rc; }
   b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1; b->whole_envs = -1;
-  if (m->dims.env_kind != rsr::ENV_GO2) {
+  if (m->dims.env_kind != rsr::ENV_GO2 && m->dims.env_kind != rsr::ENV_GO2_HANDSTAND) {
     const size_t sb = (4 + (size_t)num_envs) * sizeof(int);
     if (hipMalloc(&b->sched, sb) != hipSuccess) { b->sched = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
     (void)hipMemset(b->sched, 0, sb);
@@ -1599,7 +1920,7 @@ extern "C" int rsr_batch_set_dr_field(rsr_batch* b, int dr_field, const float* d
     case RSR_DR_DOF_DAMPING: b->dr_damp = dev_values; return RSR_OK;
     case RSR_DR_DOF_FRICTIONLOSS: b->dr_floss = dev_values; return RSR_OK;
     case RSR_DR_BODY_IPOS: case RSR_DR_QPOS0: case RSR_DR_DOF_ARMATURE: case RSR_DR_ACTUATOR_GAINPRM: case RSR_DR_ACTUATOR_BIASPRM:
-      if (b->model->dims.env_kind != rsr::ENV_GO2)
+      if (b->model->dims.env_kind != rsr::ENV_GO2 && b->model->dims.env_kind != rsr::ENV_GO2_HANDSTAND)
         return fail(RSR_ERR_UNSUPPORTED, "rsr_batch_set_dr_field: this field is per-env only in the Go2 kernels (randomize.py); the Airbot kernels take the four fields of rsr_batch_set_dr");
       b->dr_ex[dr_field - RSR_DR_BODY_IPOS] = dev_values;
       return RSR_OK;
@@ -1663,6 +1984,8 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
     rsr::launch_go2_reset(b->n, st, b->dmodel, b->model->layout, a);
+  else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
+    rsr::launch_hs_reset(b->n, st, b->dmodel, b->model->layout, a);
   else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
     hipLaunchKernelGGL((rsr::reset_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
                        b->dmodel, b->model->layout, a);
@@ -1681,6 +2004,8 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
     rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a);
+  else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
+    rsr::launch_hs_step(b->n, st, b->dmodel, b->model->layout, a);
   else {
     ++b->launch_id;
     if ((b->launch_id & 0xFFFFFFu) == 0u) {        // the flags carry 24 bits of the launch number: clear them before the number repeats
@@ -1734,7 +2059,7 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_INFO_NEW_T_POS: off = L.new_T_pos; w = 2; break;
     case RSR_F_INFO_T_POS: off = L.T_pos; w = 3; break;
     case RSR_F_INFO_XITA: off = L.xita; w = 1; break;
-    case RSR_F_INFO_GO2: off = L.go2_info; w = d.env_kind == rsr::ENV_GO2 ? 144 : 0; break;
+    case RSR_F_INFO_GO2: off = L.go2_info; w = (d.env_kind == rsr::ENV_GO2 || d.env_kind == rsr::ENV_GO2_HANDSTAND) ? 144 : 0; break;
     case RSR_F_INFO_STEPS: off = L.steps; w = 1; break;
     case RSR_F_INFO_TRUNCATION: off = L.truncation; w = 1; break;
     case RSR_F_INFO_EPISODE_DONE: off = L.episode_done; w = 1; break;
@@ -1747,8 +2072,8 @@ extern "C" int rsr_view(rsr_batch* b, int field_id, void** dev_ptr, int64_t shap
     case RSR_F_FIRST_XPOS: off = L.f_xpos; w = d.nbody * 3; break;
     case RSR_F_FIRST_SITE_XPOS: off = L.f_site_xpos; w = d.nsite * 3; break;
     case RSR_F_FIRST_OBS: off = L.f_obs; w = d.obs_dim; break;
-    case RSR_F_PRIVILEGED_OBS: off = L.priv_obs; w = d.env_kind == rsr::ENV_GO2 ? 123 : 0; break;
-    case RSR_F_FIRST_PRIVILEGED_OBS: off = L.f_priv_obs; w = d.env_kind == rsr::ENV_GO2 ? 123 : 0; break;
+    case RSR_F_PRIVILEGED_OBS: off = L.priv_obs; w = (d.env_kind == rsr::ENV_GO2 || d.env_kind == rsr::ENV_GO2_HANDSTAND) ? 123 : 0; break;
+    case RSR_F_FIRST_PRIVILEGED_OBS: off = L.f_priv_obs; w = (d.env_kind == rsr::ENV_GO2 || d.env_kind == rsr::ENV_GO2_HANDSTAND) ? 123 : 0; break;
     case RSR_F_STATS: off = L.stats; w = 4; break;
     default: return fail(RSR_ERR_ARG, "rsr_view: unknown field id");
   }

@@ -219,6 +219,32 @@ class Handstand(Joystick):
     def observation_sizes(self) -> Dict[str, tuple]:
         return {"state": (self._obs_dim,), "privileged_state": (self._priv_dim,)}
 
+    def batched(self, num_envs: int, episode_length: int = 0, auto_reset: bool = False, randomization=None) -> "HandstandBatched":
+        return HandstandBatched(self, num_envs, episode_length, auto_reset, randomization)
+
+
+class HandstandBatched(Go2Batched):
+    """State of the Handstand env: info = {step, rng, last_act} (handstand.py:139-143), obs dict with the 94-dim privileged state."""
+
+    def _make_state(self) -> State:
+        v = self._views
+        data = Go2Data(v, self.dims)
+        g = v["info_go2"]
+        info: Dict[str, Any] = {"step": g[:, 0], "last_act": g[:, 4:16], "rng": g[:, 137:139]}
+        metrics = {name: v["metrics"][:, i] for i, name in enumerate(cfg.HANDSTAND_METRICS)}
+        if self.episode_length > 0:
+            em = v["info_episode_metrics"]
+            info.update(steps=v["info_steps"][:, 0], truncation=v["info_truncation"][:, 0], episode_done=v["info_episode_done"][:, 0],
+                        episode_metrics={"sum_reward": em[:, 0], "length": em[:, 1],
+                                         **{name: em[:, 2 + i] for i, name in enumerate(cfg.HANDSTAND_METRICS)}})
+        pd = cfg.HANDSTAND_PRIV_OBS_DIM
+        if self.auto_reset:
+            info["first_obs"] = {"state": v["first_obs"], "privileged_state": v["first_privileged_obs"][:, :pd]}
+        st = State(pipeline_state=data, obs=v["obs"], reward=v["reward"][:, 0], done=v["done"][:, 0], metrics=metrics, info=info)
+        st.data = data
+        st.obs_dict = {"state": v["obs"], "privileged_state": v["privileged_obs"][:, :pd]}
+        return st
+
 
 class Footstand(Handstand):
     """reference go2/handstand.py:293-342: the mirrored task (stand on the hind feet)."""

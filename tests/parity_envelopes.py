@@ -43,12 +43,14 @@ def bound(kind, phase, field, what="max"):
     return ENV[kind][phase][field][what]
 
 
-def check(kind, phase, field, got, want, tag="", quantiles=True):
+def check(kind, phase, field, got, want, tag="", quantiles=True, outliers=0):
     """Asserts the envelope of (kind, phase, field) on the per-env scaled error of `got` against `want`; returns the errors.
     Fields without an envelope are values the step only passes through (targets, constants): exact to 1e-6.  The 99 % quantile
     is asked for on samples of >= 1000 envs (it is too noisy below); the share of envs above 1e-5 only where the measurement
     found essentially none (<= 0.2 %): there it is the north_star's own bar, elsewhere 1e-5 sits inside the bulk of the
-    distribution and the share says nothing the quantile does not."""
+    distribution and the share says nothing the quantile does not.  `outliers`: envs exempt from the hard cap of a large sample (the Go2
+    models with many contact pairs: a touch-down that falls on the other side of a step boundary is an O(1e-3) position change in a
+    one-iteration solve; the quantile clauses still hold them to one env in a thousand)."""
     err = scaled_err(got, want)
     assert np.isfinite(err).all(), (tag, kind, phase, field, "non-finite")
     if field not in ENV[kind][phase]:
@@ -59,7 +61,8 @@ def check(kind, phase, field, got, want, tag="", quantiles=True):
     # measured maximum of a 6000-sample run): in a large sample one env in a thousand may pass the bound, none may pass 30 x it;
     # a small sample is held to the bound itself -- one env may pass it, by less than 5 x
     if len(err) >= 1000:
-        assert err.max() <= 30.0 * e["max"], (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)))
+        over = int((err > 30.0 * e["max"]).sum())
+        assert over <= outliers, (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)), over)
         assert np.quantile(err, 0.999) <= e["max"], (tag, kind, phase, field, "p99.9", float(np.quantile(err, 0.999)), e["max"])
     else:
         assert int((err > e["max"]).sum()) <= 1, (tag, kind, phase, field, "envs above max in a small sample", np.nonzero(err > e["max"])[0].tolist(), e["max"])

@@ -179,3 +179,111 @@ def test_truncation_and_autoreset(oracle_mod):
             assert (st["done"] == 1).all()
             np.testing.assert_array_equal(st["qpos"], first["qpos"]); np.testing.assert_array_equal(st["obs"], first["obs"])
             np.testing.assert_array_equal(st["priv_obs"], first["priv_obs"])
+
+
+# ------------------------------------------------------------------------------------------------ GPU parity (HIP stepper vs oracle)
+GNAME = {"priv_obs": "privileged_obs", "first_priv_obs": "first_privileged_obs"}
+FIELDS = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs", "reward", "done", "metrics", "info_go2",
+          "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
+          "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs", "priv_obs", "first_priv_obs"]
+
+
+def _key(info):
+    return np.ascontiguousarray(info[:, 137:139]).view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,randomize", [("Go2Handstand", True), ("Go2Footstand", False)])
+def test_handstand_hip_parity(oracle_mod, name, randomize):
+    """Reset: the PRNG-only parts bit for bit; teacher-forced env-steps at three rollout depths inside the measured envelopes; and a
+    step from poses with the trunk lowered onto the floor (thigh / calf capsules, hip and trunk cylinders in contact: the pair kinds a
+    rollout from the home pose hardly meets), where done / contact counts must agree exactly."""
+    import torch
+    n = 1024
+    jenv = go2.load(name)
+    dr = go2.domain_randomize(jenv.sys, prng.split(prng.PRNGKey(12), n)) if randomize else None
+    env = go2.wrap_for_brax_training(jenv, n, episode_length=500, randomization_fn=(lambda sys: dr) if randomize else None)
+    assert env.observation_size == 45 and env.action_size == 12 and env.dims.ncon_max == 12
+    orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(21), n)
+    odr = None if dr is None else {{"actuator_gainprm": "gainprm", "actuator_biasprm": "biasprm"}.get(k, k): v for k, v in dr.items()}
+    st = orc.new_state(n, odr)
+    orc.reset(st, keys)
+    state = env.reset(keys)
+    torch.cuda.synchronize()
+    get = lambda k: env.view(GNAME.get(k, k)).cpu().numpy().reshape(st[k].shape)
+    for k in ("qvel", "ctrl", "first_qvel", "first_ctrl"):
+        np.testing.assert_array_equal(get(k), st[k], err_msg=k)
+    np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
+    np.testing.assert_allclose(get("qpos"), st["qpos"], atol=1e-6)
+    for k in ("obs", "priv_obs", "xpos", "site_xpos"):
+        PE.check("handstand", "reset", k, get(k), st[k], tag="after reset") if k in PE.ENV["handstand"]["reset"] else None
+    assert set(state.info) >= {"step", "rng", "last_act", "steps", "truncation"} and state.obs_dict["privileged_state"].shape == (n, 94)
+    rng = np.random.default_rng(21)
+    for depth in (0, 5, 30):
+        for _ in range(depth):
+            orc.step(st, np.clip(rng.normal(size=(n, 12)) * 0.3, -1, 1).astype(f32))
+        for k in FIELDS:
+            env.view(GNAME.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        a = np.clip(rng.normal(size=(n, 12)) * 0.3, -1, 1).astype(f32)
+        orc.step(st, a)
+        state = env.step(state, a)
+        torch.cuda.synchronize()
+        for k in ("done", "info_steps", "info_truncation", "ctrl", "time"):
+            np.testing.assert_array_equal(get(k), st[k], err_msg=f"{k} depth {depth}")
+        np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))
+        np.testing.assert_array_equal(get("info_go2")[:, :16], st["info_go2"][:, :16])            # step counter, last action
+        np.testing.assert_array_equal(get("stats")[:, 2:], st["stats"][:, 2:])                    # active / dropped contacts
+        phase = "reset" if depth == 0 else "rollout"
+        for k in ("qpos", "xpos", "site_xpos", "obs", "reward", "metrics", "qvel", "qacc_warmstart", "priv_obs"):
+            PE.check("handstand", phase, k, get(k), st[k], tag=f"{name} depth {depth}", outliers=2)
+    # ---- poses on the floor: capsules and cylinders in contact ----
+    home = jenv.sys.arrays["key_qpos"][0].astype(f32)
+    st["qpos"][:] = home; st["qvel"][:] = 0
+    z = np.linspace(0.06, 0.2, n).astype(f32)
+    st["qpos"][:, 2] = z
+    tilt = rng.normal(size=(n, 4)).astype(f32) * 0.15 + np.array([1, 0, 0, 0], f32)
+    st["qpos"][:, 3:7] = tilt / np.linalg.norm(tilt, axis=1, keepdims=True)
+    st["qpos"][:, 7:] += rng.normal(size=(n, 12)).astype(f32) * 0.2
+    st["ctrl"][:] = st["qpos"][:, 7:]; st["qacc_warmstart"][:] = 0; st["done"][:] = 0
+    for k in FIELDS:
+        env.view(GNAME.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+    a = np.zeros((n, 12), f32)
+    orc.step(st, a); state = env.step(state, a)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(get("done"), st["done"])
+    np.testing.assert_array_equal(get("stats")[:, 2:], st["stats"][:, 2:])
+    assert (st["stats"][:, 2] > 4).mean() > 0.5 and (st["stats"][:, 3] > 0).any()      # capsule / cylinder contacts, and the cap of 12 is met
+    assert st["done"].mean() > 0.5
+    for k in ("reward", "metrics"):                                                     # computed from the (pre-reset) step on both sides
+        PE.check("handstand", "rollout", k, get(k), st[k], tag="floor poses", quantiles=False, outliers=2)      # (violent states: the bound, not the rollout's quantiles)
+
+
+@pytest.mark.gpu
+def test_handstand_truncation_and_autoreset_on_device(oracle_mod):
+    import torch
+    n, L = 1024, 5
+    env = go2.wrap_for_brax_training(go2.load("Go2Handstand"), n, episode_length=L)
+    orc = oracle_mod.Oracle(env.blob); orc.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(41), n)
+    st = orc.new_state(n); orc.reset(st, keys)
+    state = env.reset(keys)
+    get = lambda k: env.view(GNAME.get(k, k)).cpu().numpy().reshape(st[k].shape)
+    first_obs, first_qpos = st["first_obs"].copy(), st["first_qpos"].copy()
+    rng = np.random.default_rng(41)
+    for t in range(1, 2 * L + 1):
+        for k in FIELDS:
+            env.view(GNAME.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        a = np.clip(rng.normal(size=(n, 12)) * 0.3, -1, 1).astype(f32)
+        orc.step(st, a); state = env.step(state, a)
+        torch.cuda.synchronize()
+        for k in ("done", "info_steps", "info_truncation", "info_episode_done", "ctrl", "time"):
+            np.testing.assert_array_equal(get(k), st[k], err_msg=f"{k} at step {t}")
+        done = st["done"] != 0
+        if done.any():
+            np.testing.assert_array_equal(get("obs")[done], first_obs[done])
+            np.testing.assert_array_equal(get("qpos")[done], first_qpos[done])
+        if t % L == 0:
+            assert done.all() and (st["info_truncation"][st["info_steps"] == L] >= 0).all()
+        em = PE.scaled_err(get("info_episode_metrics"), st["info_episode_metrics"])
+        assert np.quantile(em, 0.99) <= 1e-4, (t, float(np.quantile(em, 0.99)))

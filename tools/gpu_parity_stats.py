@@ -1,7 +1,7 @@
 """Distribution of the scaled error of the HIP stepper against the fp32 CPU oracle (and of both against the fp64 oracle) on
 teacher-forced single env-steps at several rollout depths, for all four workloads.  The numbers are what the per-field
 envelopes of tests/parity_envelopes.py are derived from (x3 on the measured maximum / quantiles).
-usage: python tools/gpu_parity_stats.py [cube|tshape|go2|go2rough ...] [--n N] [--json out.json]
+usage: python tools/gpu_parity_stats.py [cube|sf|tshape|go2|go2rough|handstand ...] [--n N] [--json out.json]
 err = |a - b| / max(1, |b|_inf of that env's field), per env."""
 import json, os, sys
 import numpy as np
@@ -32,12 +32,15 @@ def make(kind, n):
         fields += ["info_xita", "info_new_T_pos", "info_T_pos"] if kind == "tshape" else ["info_new_cube_pos", "info_site_pos", "info_cube_pos"]
     else:
         from rsr_mjx_amd.envs import go2
-        jenv = go2.load("Go2JoystickRoughTerrain" if kind == "go2rough" else "Go2JoystickFlatTerrain",
-                        config_overrides={"pert_config": {"enable": True, "kick_wait_times": [0.1, 0.4], "velocity_kick": [1.0, 4.0]}})
+        if kind == "handstand":
+            jenv = go2.load("Go2Handstand")
+        else:
+            jenv = go2.load("Go2JoystickRoughTerrain" if kind == "go2rough" else "Go2JoystickFlatTerrain",
+                            config_overrides={"pert_config": {"enable": True, "kick_wait_times": [0.1, 0.4], "velocity_kick": [1.0, 4.0]}})
         dr = go2.domain_randomize(jenv.sys, prng.split(prng.PRNGKey(12), n))
-        env = go2.wrap_for_brax_training(jenv, n, episode_length=1000, randomization_fn=lambda sys: dr)
+        env = go2.wrap_for_brax_training(jenv, n, episode_length=500 if kind == "handstand" else 1000, randomization_fn=lambda sys: dr)
         odr = {{"actuator_gainprm": "gainprm", "actuator_biasprm": "biasprm"}.get(k, k): v for k, v in dr.items()}
-        nu, astd, depths = 12, 0.5, (0, 5, 40)
+        nu, astd, depths = 12, (0.3 if kind == "handstand" else 0.5), (0, 5, 40)
         fields = ["qpos", "qvel", "qacc_warmstart", "xpos", "site_xpos", "obs", "reward", "metrics", "priv_obs"]
     return env, odr, nu, astd, depths, fields
 
@@ -46,7 +49,7 @@ def main():
     args = sys.argv[1:]
     n = int(args[args.index("--n") + 1]) if "--n" in args else 2048
     out_json = args[args.index("--json") + 1] if "--json" in args else None
-    kinds = [a for a in args if a in ("cube", "sf", "tshape", "go2", "go2rough")] or ["cube", "sf", "tshape", "go2", "go2rough"]
+    kinds = [a for a in args if a in ("cube", "sf", "tshape", "go2", "go2rough", "handstand")] or ["cube", "sf", "tshape", "go2", "go2rough", "handstand"]
     result = {}
     for kind in kinds:
         env, odr, nu, astd, depths, fields = make(kind, n)
