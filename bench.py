@@ -300,7 +300,7 @@ def main():
     timeouts = env.handoff_timeouts()         # outside the timed region: the work queue's sticky error word (0 on a healthy run)
 
     if rank == 0:
-        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536, "handstand": 1788}[args.workload]
+        bytes_per = {"cube": BYTES_PER_ENV_STEP if args.no_dr else BYTES_PER_ENV_STEP_DR, "tshape": 560, "go2": 2536, "go2rough": 2536, "handstand": 1580}[args.workload]
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bytes_per * n / avg_launch_s
         stats = env.view("stats").float().mean(dim=0).tolist()

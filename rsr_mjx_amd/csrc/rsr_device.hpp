@@ -587,13 +587,21 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
     }
   }
   PROF(PS_K_LOCAL)
-  // compose down the tree: after level d every body of depth <= d holds its world pose
+  // Compose down the tree by pointer jumping: every body holds its pose relative to an ancestor `anc`, and a round composes it
+  // with that ancestor's own (pose relative to ITS ancestor) and jumps: anc <- anc of anc.  After r rounds a body is expressed
+  // relative to its 2^r-th ancestor, the world being its own ancestor with the identity pose (composing with the identity is
+  // exact, so bodies that have arrived keep their bits): ceil(log2(maxdepth)) rounds of cross-lane reads and one composition
+  // each instead of maxdepth rounds (cube: 4 instead of 9, 14 of 64 lanes busy either way).  Same products, associated pairwise
+  // instead of root-to-leaf: results differ from the sequential composition in the last bit or two.
   V3 pos = lane == 0 ? v3(0, 0, 0) : lp;
   Q4 q = lane == 0 ? Q4{1, 0, 0, 0} : lq;
-  for (int d = 1; d <= h.maxdepth; ++d) {
-    V3 pp = v3(__shfl(pos.x, parent), __shfl(pos.y, parent), __shfl(pos.z, parent));
-    Q4 pq = Q4{__shfl(q.w, parent), __shfl(q.x, parent), __shfl(q.y, parent), __shfl(q.z, parent)};
-    if (depth == d) { pos = pp + qrot(pq, lp); q = qmul(pq, lq); }
+  int anc = (lane < C::NB && lane > 0) ? parent : 0;
+  for (int span = 1; span < h.maxdepth; span *= 2) {
+    V3 pp = v3(__shfl(pos.x, anc), __shfl(pos.y, anc), __shfl(pos.z, anc));
+    Q4 pq = Q4{__shfl(q.w, anc), __shfl(q.x, anc), __shfl(q.y, anc), __shfl(q.z, anc)};
+    const int anc2 = __shfl(anc, anc);
+    pos = pp + qrot(pq, pos); q = qmul(pq, q);
+    anc = anc2;
   }
   PROF(PS_K_TREE)
   if (lane < C::NB) {
