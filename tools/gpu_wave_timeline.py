@@ -48,7 +48,8 @@ cyc = raw[:, 4]; hw = raw[:, 5]; xcc = raw[:, 6] & 0xF
 if whole is not None:
     # envs stepped as one unit write slot 0 only: keep the units that ran in the last launch
     ran = rt0 >= rt0[rt0 > 0].max() - 300000            # within 3 ms of the latest start
-    is_whole = np.tile(np.arange(n) < (whole if whole >= 0 else 0), units)
+    n_whole = whole if whole >= 0 else max(0, n - 2 * 2048)       # the library's default: all but two resident rounds (8 waves x 256 CUs)
+    is_whole = np.tile(np.arange(n) < n_whole, units)
     for name, sel in (("whole-step units", ran & is_whole), ("split units", ran & ~is_whole)):
         if sel.any():
             print(f"{name}: {int(sel.sum())}, lifetime mean {((rt1[sel] - rt0[sel]) / 100.0).mean():.1f} us p99 {np.percentile((rt1[sel] - rt0[sel]) / 100.0, 99):.1f}, start {((rt0[sel] - rt0[ran].min()) / 100.0).min():.1f}..{((rt0[sel] - rt0[ran].min()) / 100.0).max():.1f} us")
