@@ -1359,15 +1359,17 @@ static void linesearch(const omodel *m, odata *d, sctx *c, real *jv, real *quad)
     int done = it >= cap;
     done |= !swap;
     real tol_lo = gtol, tol_hi = gtol;
-    if (noise > 0) {
-      real a = noise * (n1 + 2 * (real)fabs((double)lo.alpha) * n2), b = noise * (n1 + 2 * (real)fabs((double)hi.alpha) * n2);
-      if (a > tol_lo) tol_lo = a;
-      if (b > tol_hi) tol_hi = b;
-    }
     if (g_ls_rule == 2 && noise > 0) {
-      done |= (real)fabs((double)lo.deriv0) < tol_lo;
-      done |= (real)fabs((double)hi.deriv0) < tol_hi;
+      /* the kernel's rule: MJX's signed test for MJX's tolerance, and -- sign-free -- the rounding noise of the derivative's own sum */
+      real a = noise * (n1 + 2 * (real)fabs((double)lo.alpha) * n2), b = noise * (n1 + 2 * (real)fabs((double)hi.alpha) * n2);
+      done |= ((lo.deriv0 < 0) && (lo.deriv0 > -gtol)) || ((real)fabs((double)lo.deriv0) < a);
+      done |= ((hi.deriv0 > 0) && (hi.deriv0 < gtol)) || ((real)fabs((double)hi.deriv0) < b);
     } else {
+      if (noise > 0) {       /* rule 1: the noise floor as a larger tolerance of the signed test */
+        real a = noise * (n1 + 2 * (real)fabs((double)lo.alpha) * n2), b = noise * (n1 + 2 * (real)fabs((double)hi.alpha) * n2);
+        if (a > tol_lo) tol_lo = a;
+        if (b > tol_hi) tol_hi = b;
+      }
       done |= (lo.deriv0 < 0) && (lo.deriv0 > -tol_lo);
       done |= (hi.deriv0 > 0) && (hi.deriv0 < tol_hi);
     }

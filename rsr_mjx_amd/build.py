@@ -11,9 +11,10 @@ LIB = os.path.join(CSRC, "librsrmjx.so")
 SOURCES = ["rsr_mjx.hip"]
 HEADERS = ["rsr_device.hpp", "rsr_solver.hpp", os.path.join("..", "..", "include", "rsr_mjx.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-# Two translation units from the one source: the Airbot kernels + the C ABI, and the Go2 kernels with the SLP vectoriser off
-# (its packed-fp32 pairing costs the Go2 kernels ~3% and gains the Airbot kernels ~1%; measured A/B on one box).
-UNITS = [("rsr_main.o", []), ("rsr_go2.o", ["-DRSR_TU_GO2", "-fno-slp-vectorize"])]
+# Three translation units from the one source: the cube kernels + the C ABI; the T-shape kernels and the Go2 kernels each on their own
+# with the SLP vectoriser off (its packed-fp32 pairing costs the Go2 and T-shape kernels ~3 % and gains the cube kernels ~0.5 %;
+# measured A/B on one box).  Kernels of one unit also perturb each other's register allocation: a unit holds one model family.
+UNITS = [("rsr_main.o", []), ("rsr_tshape.o", ["-DRSR_TU_TSHAPE", "-fno-slp-vectorize"]), ("rsr_go2.o", ["-DRSR_TU_GO2", "-fno-slp-vectorize"])]
 
 
 def _stale(lib: str) -> bool:

@@ -1508,6 +1508,22 @@ void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArg
 void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+// The T-shape kernels likewise (-DRSR_TU_TSHAPE -fno-slp-vectorize: +3 % for them, measured; the cube kernels keep the vectoriser).
+void launch_tshape_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+void launch_tshape_step(int grid, hipStream_t st, const DModel* dm, Layout L, StepArgs a, Sched sc);
+int tshape_step_occupancy();
+#ifdef RSR_TU_TSHAPE
+void launch_tshape_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
+  hipLaunchKernelGGL((reset_kernel<TShapeDims, ENV_TSHAPE>), dim3(n), dim3(64), sizeof(Smem<TShapeDims>), st, dm, L, a);
+}
+void launch_tshape_step(int grid, hipStream_t st, const DModel* dm, Layout L, StepArgs a, Sched sc) {
+  hipLaunchKernelGGL((step_kernel<TShapeDims, ENV_TSHAPE>), dim3(grid), dim3(64), sizeof(Smem<TShapeDims>), st, dm, L, a, sc);
+}
+int tshape_step_occupancy() {
+  int per_cu = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, step_kernel<TShapeDims, ENV_TSHAPE>, 64, sizeof(Smem<TShapeDims>)) == hipSuccess ? per_cu : 0;
+}
+#endif
 #ifdef RSR_TU_GO2
 void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
   hipLaunchKernelGGL((hs_reset_kernel<HandDims>), dim3(n), dim3(64), sizeof(Smem<HandDims>), st, dm, L, a);
@@ -1523,7 +1539,7 @@ void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs
 }
 #endif
 
-#ifndef RSR_TU_GO2
+#if !defined(RSR_TU_GO2) && !defined(RSR_TU_TSHAPE)
 // ---------------------------------------------------------------- end-of-rollout metric reduction
 // One launch instead of a handful of library reductions: out = {envs, sum of reward, sum of done, mean of the running episode's
 // summed reward} over the batch, summed in a fixed order (per-thread strided partial sums, then a binary tree in LDS), so the
@@ -1548,7 +1564,7 @@ __global__ __launch_bounds__(1024) void rollout_metrics_kernel(const float* __re
 
 }  // namespace rsr
 
-#ifndef RSR_TU_GO2
+#if !defined(RSR_TU_GO2) && !defined(RSR_TU_TSHAPE)
 // =====================================================================================
 // host side: C ABI
 // =====================================================================================
@@ -1873,9 +1889,9 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     (void)hipMemset(b->sched, 0, sb);
     // resident waves of the step kernel on this device: the grid of the persistent launch
     int per_cu = 0; hipDeviceProp_t prop;
-    hipError_t oe = m->dims.env_kind == rsr::ENV_TSHAPE
-      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>, 64, sizeof(rsr::Smem<rsr::TShapeDims>))
-      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>, 64, sizeof(rsr::Smem<rsr::CubeDims>));
+    hipError_t oe = hipSuccess;
+    if (m->dims.env_kind == rsr::ENV_TSHAPE) per_cu = rsr::tshape_step_occupancy();
+    else oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>, 64, sizeof(rsr::Smem<rsr::CubeDims>));
     if (oe != hipSuccess || hipGetDeviceProperties(&prop, hip_device) != hipSuccess || per_cu <= 0) { per_cu = 8; prop.multiProcessorCount = 256; }
     if (const char* gv = std::getenv("RSR_GRID_PER_CU")) { const int g = std::atoi(gv); if (g > 0 && g < per_cu) per_cu = g; }   // diagnostic: fewer resident waves
     b->step_grid = per_cu * prop.multiProcessorCount;
@@ -1987,8 +2003,7 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
     rsr::launch_hs_reset(b->n, st, b->dmodel, b->model->layout, a);
   else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
-    hipLaunchKernelGGL((rsr::reset_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
-                       b->dmodel, b->model->layout, a);
+    rsr::launch_tshape_reset(b->n, st, b->dmodel, b->model->layout, a);
   else
     hipLaunchKernelGGL((rsr::reset_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(b->n), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
                        b->dmodel, b->model->layout, a);
@@ -2020,8 +2035,7 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
     const long long work = (long long)n_whole + (long long)b->units * (b->n - n_whole);
     const int grid = (int)(work > b->step_grid ? b->step_grid : work);
     if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
-      hipLaunchKernelGGL((rsr::step_kernel<rsr::TShapeDims, rsr::ENV_TSHAPE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::TShapeDims>), st,
-                         b->dmodel, b->model->layout, a, sc);
+      rsr::launch_tshape_step(grid, st, b->dmodel, b->model->layout, a, sc);
     else
       hipLaunchKernelGGL((rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
                          b->dmodel, b->model->layout, a, sc);
@@ -2109,4 +2123,4 @@ extern "C" int rsr_timing_end(rsr_batch* b, void* hip_stream, float* total_ms, i
   b->timing = false;
   return RSR_OK;
 }
-#endif  // !RSR_TU_GO2
+#endif  // the host unit

@@ -576,15 +576,11 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
       const float lo_d0 = lo.d0(), hi_d0 = hi.d0();
       bool ldone = it >= cap;
       ldone |= !swap;
-      float tol_lo = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(lo.alpha) * n2));
-      float tol_hi = fmaxf(gtol, NOISE * (n1 + 2.0f * fabsf(hi.alpha) * n2));
-      if (NOISE > 0.0f) {     // below the rounding noise of its own sum the derivative has no sign
-        ldone |= fabsf(lo_d0) < tol_lo;
-        ldone |= fabsf(hi_d0) < tol_hi;
-      } else {
-        ldone |= (lo_d0 < 0.0f) && (lo_d0 > -tol_lo);
-        ldone |= (hi_d0 > 0.0f) && (hi_d0 < tol_hi);
-      }
+      // MJX's own test, signs included, for its tolerance; below the rounding noise of its own sum the derivative has no sign, so the
+      // noise-floor term asks for the magnitude only (NOISE = 0, the single-iteration models: MJX's rule alone)
+      const float nz_lo = NOISE * (n1 + 2.0f * fabsf(lo.alpha) * n2), nz_hi = NOISE * (n1 + 2.0f * fabsf(hi.alpha) * n2);
+      ldone |= ((lo_d0 < 0.0f) && (lo_d0 > -gtol)) || (fabsf(lo_d0) < nz_lo);
+      ldone |= ((hi_d0 > 0.0f) && (hi_d0 < gtol)) || (fabsf(hi_d0) < nz_hi);
       if (uniform_i(ldone)) break;
       float al3[3] = {lo.alpha - lo_d0 * __builtin_amdgcn_rcpf(lo.d1()), hi.alpha - hi_d0 * __builtin_amdgcn_rcpf(hi.d1()), 0.5f * (lo.alpha + hi.alpha)};
       LSPoint p3[3];
