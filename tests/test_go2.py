@@ -1,10 +1,12 @@
 """Go2 joystick env: model structure, reset / PRNG consumption, step bookkeeping and the reward terms that are
 functions of recorded state, restated in numpy from reference go2/joystick.py; plus HIP parity (gpu)."""
+import os
+
 import numpy as np
 import pytest
 
 import parity_envelopes as PE
-from conftest import make_go2_blob
+from conftest import ROOT, make_go2_blob
 from rsr_mjx_amd import mjcf, prng
 from rsr_mjx_amd.envs import config as cfg
 
@@ -383,10 +385,18 @@ def test_go2_hip_parity(oracle_mod, task, randomize, kicks):
                     orc.step(sp, a)
                     sens = max(sens, float(serr(sp[k], st[k])[w]))
                 assert eg[w] <= 3.0 * sens + 1e-4, (depth, k, int(w), float(eg[w]), sens)
-    # discontinuous states are rare: at most 1 % of the (env, field, depth) samples of the rough-terrain case take the way out
+    # discontinuous states are rare: at most 1 % of the (env, field, depth) samples of the rough-terrain case take the way out,
+    # and not more than was recorded when the count was last looked at (tests/golden/rough_hatch.json; the count of this run goes
+    # to gpurun_out/rough_hatch_count.json, from where the round's evidence copies it to profiles/)
     assert hatch_count <= 0.01 * n * 9 * 3, hatch_count
     if task == "Rough":
+        import json
         print(f"rough-terrain discontinuity hatch taken by {hatch_count} (env, field) samples of {n * 9 * 3}")
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump({"hatch_count": hatch_count, "samples": n * 9 * 3, "envs": n, "fields": 9, "depths": 3},
+                  open(os.path.join(ROOT, "gpurun_out", "rough_hatch_count.json"), "w"))
+        rec = json.load(open(os.path.join(ROOT, "tests", "golden", "rough_hatch.json")))
+        assert hatch_count <= rec["hatch_count"] + max(3, rec["hatch_count"] // 2), (hatch_count, rec)
     assert set(state.info) >= {"command", "last_act", "feet_air_time", "action_buffer", "gyro_buffer", "rng", "steps", "truncation"}
     assert state.info["action_buffer"].shape == (n, 4, 12) and len(state.metrics) == 22
 
