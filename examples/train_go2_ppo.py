@@ -1,9 +1,11 @@
-"""PPO on Go2JoystickFlatTerrain / RoughTerrain with the hyper-parameters of reference
-ppo_train/go2_training/mujoco_playground/config/locomotion_params.py:5-41 (8192 envs, unroll 20, batch 256 x 32 minibatches x 4
+"""PPO on Go2JoystickFlatTerrain / RoughTerrain / Go2Handstand / Go2Footstand with the hyper-parameters of reference
+ppo_train/go2_training/mujoco_playground/config/locomotion_params.py:5-50 (8192 envs, unroll 20, batch 256 x 32 minibatches x 4
 updates, lr 3e-4, entropy 1e-2, discount 0.97, max_grad_norm 1.0, policy / value MLPs (512, 256, 128), the critic on
-`privileged_state`), with the domain randomisation of go2/randomize.py, on the HIP stepper and the torch learner.
+`privileged_state`; episode length from the env's config: 1000 joystick, 500 handstand), with the domain randomisation of
+go2/randomize.py, on the HIP stepper and the torch learner.
 
-  python examples/train_go2_ppo.py --timesteps 200000000        # the reference's budget
+  python examples/train_go2_ppo.py --timesteps 200000000                       # the reference's budget (joystick)
+  python examples/train_go2_ppo.py --env Go2Handstand --timesteps 100000000    # (handstand / footstand: :42-50)
 """
 import argparse
 import os
@@ -31,7 +33,8 @@ def main():
               f"  len {m['eval/avg_episode_length']:6.1f}" + (f"  train sps {m['training/sps']:,.0f}" if "training/sps" in m else ""), flush=True)
 
     wrap = lambda env, n, ep, rf: go2.wrap_for_brax_training(env, n, episode_length=ep, randomization_fn=rf)
-    train(go2.load(args.env), num_timesteps=args.timesteps, num_evals=args.evals, reward_scaling=1.0, episode_length=1000,
+    env = go2.load(args.env)
+    train(env, num_timesteps=args.timesteps, num_evals=args.evals, reward_scaling=1.0, episode_length=int(env._config["episode_length"]),
           normalize_observations=True, action_repeat=1, unroll_length=20, num_minibatches=32, num_updates_per_batch=4, discounting=0.97,
           learning_rate=3e-4, entropy_cost=1e-2, num_envs=args.num_envs, batch_size=256, max_grad_norm=1.0, rsr_loss_scale=0.0,
           policy_hidden_layer_sizes=(512, 256, 128), value_hidden_layer_sizes=(512, 256, 128), value_obs_key="privileged_state",
