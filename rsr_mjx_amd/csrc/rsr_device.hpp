@@ -488,7 +488,8 @@ struct Smem {
   float jtp[C::NBC * C::NCON > 16 ? 64 : 1];           // J^T f: partial sums of the row groups (lane = group * NV + dof)
   float bval[C::NBASE + 4];                            // per base row: J.v or the force folded onto the base row
   float wc[C::NCON * 8];                               // per contact: arrow-matrix weights of the Hessian (2*NBC-1 used)
-  float rw[C::NEFC + 4];                               // per pyramid row: Hessian weight D*active or force
+  alignas(16) float rw[C::NEFC + 4];                   // per pyramid row: Hessian weight D*active or force; between uses its first words
+                                                       // are the broadcast buffer of vec_bcast (b128 reads: hence the alignment)
   union X { PhaseA<C> a; PhaseB<C> b; } x;
 };
 
@@ -1188,15 +1189,32 @@ __device__ __forceinline__ float arrow_solve(const float (&a)[C::NCH], const flo
   return __shfl(x, lane < C::NV ? arrow_lane<C>(lane) : 0);
 }
 
-// broadcast a per-dof vector (lane i holds v_i) and multiply by a register-resident matrix row
+// A per-dof vector (lane i holds v_i) to every lane: through LDS -- one store, NV/4 uniform-address ds_read_b128 (broadcast reads) --
+// instead of NV v_readlane into NV scalar registers.  The products that follow (M.v and J.v of the same vector) then take their
+// operands from vector registers: the solver's loops are short of SGPRs (their spills are v_writelane / v_readlane pairs in the
+// Newton loop's head), and a readlane needs wait states after the VALU write of its source.  The buffer is the head of the row-weight
+// array, which is dead wherever a vector is broadcast (its users rewrite what they read: hessian_factor, jt_force, make_constraint).
+template <class C> constexpr int NVP = (C::NV + 3) / 4 * 4;
 template <class C>
-__device__ __forceinline__ float row_dot(const float (&row)[C::NV], float v) {
+__device__ __forceinline__ void vec_bcast(Smem<C>& s, int lane, float v, float (&vb)[NVP<C>]) {
+  static_assert(NVP<C> <= C::NEFC, "the broadcast buffer is the head of rw");
+  WSYNC();
+  if (lane < NVP<C>) s.rw[lane] = lane < C::NV ? v : 0.0f;
+  WSYNC();
+  const float4* p = reinterpret_cast<const float4*>(&s.rw[0]);
+#pragma unroll
+  for (int k = 0; k < NVP<C> / 4; ++k) { const float4 t = p[k]; vb[4 * k] = t.x; vb[4 * k + 1] = t.y; vb[4 * k + 2] = t.z; vb[4 * k + 3] = t.w; }
+  WSYNC();
+}
+// row . broadcast vector
+template <class C>
+__device__ __forceinline__ float row_dot(const float (&row)[C::NV], const float (&vb)[NVP<C>]) {
   // even and odd terms in the two halves of one packed accumulator: NV/2 v_pk_fma_f32 instead of NV v_fma_f32 (without
   // fast-math the compiler may not split the serial sum itself)
   static_assert(C::NV % 2 == 0, "paired dot product assumes an even dof count");
   v2f acc = {0.0f, 0.0f};
 #pragma unroll
-  for (int j = 0; j < C::NV; j += 2) acc = __builtin_elementwise_fma((v2f){row[j], row[j + 1]}, (v2f){rdlane(v, j), rdlane(v, j + 1)}, acc);
+  for (int j = 0; j < C::NV; j += 2) acc = __builtin_elementwise_fma((v2f){row[j], row[j + 1]}, (v2f){vb[j], vb[j + 1]}, acc);
   return acc.x + acc.y;
 }
 

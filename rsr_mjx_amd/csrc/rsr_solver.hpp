@@ -11,14 +11,11 @@ namespace rsr {
 template <class C>
 struct DofRegs { float qacc, Ma, grad, search, mv, qfc; };
 
-// J * v for the pyramid rows owned by this lane (v: per-dof vector, lane i holds v_i): dot products with the
+// J * v for the pyramid rows owned by this lane (vb: the per-dof vector broadcast to every lane, vec_bcast): dot products with the
 // base rows (lane = base row), published through LDS, then combined as base[bn] + mu * base[bk].
 template <class C>
-__device__ __forceinline__ void jdot(Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK], float v,
+__device__ __forceinline__ void jdot(Smem<C>& s, int lane, int nefc, int nbase, const RowRegs (&rr)[C::NCHUNK], const float (&vb)[NVP<C>],
                                      float (&out)[C::NCHUNK]) {
-  float vb[C::NV];
-#pragma unroll
-  for (int i = 0; i < C::NV; ++i) vb[i] = rdlane(v, i);
   WSYNC();
 #pragma unroll
   for (int ch = 0; ch < C::NCHB; ++ch) {
@@ -440,14 +437,17 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   // wins almost always, and its context (row cost, Gauss term, force, hw) is then already there instead of being
   // evaluated a third time.
   if constexpr (C::MROW_LDS) load_mrow<C>(s, lane, Mrow);
-  float Ma_s = dofl ? row_dot<C>(Mrow, a0) : 0.0f;
+  float vb[NVP<C>];
+  vec_bcast<C>(s, lane, a0, vb);
+  float Ma_s = dofl ? row_dot<C>(Mrow, vb) : 0.0f;
   float jar_s[C::NCHUNK];
-  jdot<C>(s, lane, nefc, nbase, rr, a0, tmp);
+  jdot<C>(s, lane, nefc, nbase, rr, vb, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jar_s[ch] = tmp[ch] - rr[ch].aref;
   const float cost_s = rows_cost<C>(lane, nefc, jar_s, rr, force, hw);      // (its Gauss term (Ma_s - fs).(a0 - a0) is zero)
-  float Ma_w = dofl ? row_dot<C>(Mrow, warm) : 0.0f;
-  jdot<C>(s, lane, nefc, nbase, rr, warm, tmp);
+  vec_bcast<C>(s, lane, warm, vb);
+  float Ma_w = dofl ? row_dot<C>(Mrow, vb) : 0.0f;
+  jdot<C>(s, lane, nefc, nbase, rr, vb, tmp);
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) jaref[ch] = tmp[ch] - rr[ch].aref;
   float rows_w = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw), gs_w = dofl ? (Ma_w - fs) * (warm - a0) : 0.0f, unused = 0.0f;
@@ -515,8 +515,10 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     PROF(PS_HESS)
     // ---------------- line search ----------------
     if constexpr (C::MROW_LDS) load_mrow<C>(s, lane, Mrow);
-    float mv = dofl ? row_dot<C>(Mrow, search) : 0.0f;
-    jdot<C>(s, lane, nefc, nbase, rr, search, jv);
+    float sb[NVP<C>];
+    vec_bcast<C>(s, lane, search, sb);
+    float mv = dofl ? row_dot<C>(Mrow, sb) : 0.0f;
+    jdot<C>(s, lane, nefc, nbase, rr, sb, jv);
     float snorm = search * search, g1a = search * Ma, g1b = search * fs;
     wave_sum3(snorm, g1a, g1b);
     snorm = sqrtf(snorm);
@@ -677,7 +679,11 @@ __device__ __forceinline__ void forward(const DModel& m, const Hot& h, Smem<C>& 
   float bcoef[C::NCHUNK], jqv[C::NCHUNK];
   int nbase;
   int nefc = make_constraint<C>(m, h, s, lane, rr, bcoef, nbase PROF_PASS);
-  jdot<C>(s, lane, nefc, nbase, rr, qvel_i, jqv);                 // aref = -b (J.qvel) - k imp pos
+  {
+    float qb[NVP<C>];
+    vec_bcast<C>(s, lane, qvel_i, qb);
+    jdot<C>(s, lane, nefc, nbase, rr, qb, jqv);                   // aref = -b (J.qvel) - k imp pos
+  }
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) rr[ch].aref -= bcoef[ch] * jqv[ch];
   PROF(PS_ROWS)
