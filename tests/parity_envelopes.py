@@ -47,7 +47,7 @@ def check(kind, phase, field, got, want, tag="", quantiles=True, outliers=0):
     """Asserts the envelope of (kind, phase, field) on the per-env scaled error of `got` against `want`; returns the errors.
     Fields without an envelope are values the step only passes through (targets, constants): exact to 1e-6.  The 99 % quantile
     is asked for on samples of >= 1000 envs (it is too noisy below); the share of envs above 1e-5 only where the measurement
-    found essentially none (<= 0.2 %): there it is the north_star's own bar, elsewhere 1e-5 sits inside the bulk of the
+    found essentially none (<= 0.2 %; the bound is the envelope's `frac`, 3 x that + 1 %): there it is the north_star's own bar, elsewhere 1e-5 sits inside the bulk of the
     distribution and the share says nothing the quantile does not.  `outliers`: envs exempt from the hard cap of a large sample (the Go2
     models with many contact pairs: a touch-down that falls on the other side of a step boundary is an O(1e-3) position change in a
     one-iteration solve; the quantile clauses still hold them to one env in a thousand)."""
@@ -70,5 +70,5 @@ def check(kind, phase, field, got, want, tag="", quantiles=True, outliers=0):
     if quantiles and len(err) >= 1000:
         assert np.quantile(err, 0.99) <= e["p99"], (tag, kind, phase, field, "p99", float(np.quantile(err, 0.99)), e["p99"])
     if quantiles and len(err) >= 200 and e["measured"]["frac"] <= 0.002:
-        assert np.mean(err > 1e-5) <= 0.01, (tag, kind, phase, field, "share above 1e-5", float(np.mean(err > 1e-5)))
+        assert np.mean(err > 1e-5) <= e["frac"], (tag, kind, phase, field, "share above 1e-5", float(np.mean(err > 1e-5)), e["frac"])
     return err
