@@ -325,6 +325,16 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 __device__ __forceinline__ int rdlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Reciprocal, reciprocal square root and square root of the geometry / dynamics stages: the hardware approximation (1 ulp) plus one
+// Newton step for the reciprocals -- 3-4 instructions -- instead of the IEEE expansions of `/` and sqrtf() (v_div_scale x 2, v_rcp,
+// four fma, v_div_fmas, v_div_fixup: 10-11 dependent instructions per division, ~45 divisions per substep of the cube model).
+// Results are within ~1 ulp of the correctly rounded ones: the same order as the fma contraction the kernels already differ from the
+// oracle by.  The env algebra (prologue, rewards, observations: the reference's op-by-op JAX-CPU arithmetic) and the solver's norms keep `/` and sqrtf().
+// Arguments: finite, non-zero (frcp, frsq: > 0); fsqrt: >= 0, and values below the normal range count as zero (every caller tests
+// its norm against RSR_MINVAL or adds a floor).
+__device__ __forceinline__ float frcp(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r); }
+__device__ __forceinline__ float frsq(float x) { const float r = __builtin_amdgcn_rsqf(x); return __builtin_fmaf(r, __builtin_fmaf(-(x * r), 0.5f * r, 0.5f), r); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 // One wave is one workgroup, so a "barrier" only has to order this wave's own LDS accesses.  The LDS executes a wave's
 // instructions in order -- a read issued after a write of the same wave observes it -- so a wavefront-scope fence is enough: it
 // stops the compiler from moving memory operations across it and emits no instruction.  (__syncthreads() in a one-wave
@@ -567,9 +577,9 @@ __device__ __forceinline__ void kinematics(const DModel& m, const Hot& h, Smem<C
     if (jt == JNT_FREE) {
       lp = ld3(&s.qpos[qa]);
       lq = ld4(&s.qpos[qa + 3]);
-      float n = sqrtf(lq.w * lq.w + lq.x * lq.x + lq.y * lq.y + lq.z * lq.z);
+      float n = fsqrt(lq.w * lq.w + lq.x * lq.x + lq.y * lq.y + lq.z * lq.z);
       if (n < RSR_MINVAL) lq = Q4{1, 0, 0, 0};
-      else { float inv = 1.0f / n; lq = Q4{lq.w * inv, lq.x * inv, lq.y * inv, lq.z * inv}; }
+      else { float inv = frcp(n); lq = Q4{lq.w * inv, lq.x * inv, lq.y * inv, lq.z * inv}; }
       st4(&s.qpos[qa + 3], lq);                    // MJX writes the normalised quaternion back
     } else {
       V3 jp = v3_xyz(rb_jpos), jax = V3{asf(rb_jpos.w), asf(rb_jax.x), asf(rb_jax.y)};
@@ -766,7 +776,7 @@ __device__ __forceinline__ void com_crb_mass(const DModel& m, const Hot& h, Smem
     acc.y += dpp_mov<0xB1>(acc.y); acc.y += dpp_mov<0x4E>(acc.y);
     acc.z += dpp_mov<0xB1>(acc.z); acc.z += dpp_mov<0x4E>(acc.z);
     if (g == 0 && qb < C::NB) {
-      V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * qb]) : acc * (1.0f / mm);
+      V3 c = mm < RSR_MINVAL ? ld3(&s.x.a.xipos[3 * qb]) : acc * frcp(mm);
       st3(&s.com[3 * qb], c);
     }
   }
@@ -1222,12 +1232,12 @@ __device__ __forceinline__ float row_dot(const float (&row)[C::NV], const float 
 // stage 4: collision (lane = geom pair); penetrating contacts are compacted into the LDS list
 // =====================================================================================
 __device__ __forceinline__ void make_frame(V3 n, V3& a, V3& b, V3& c) {
-  float nn = sqrtf(dot(n, n));
-  a = nn > RSR_MINVAL ? n * (1.0f / nn) : v3(0, 0, 0);
+  float nn = fsqrt(dot(n, n));
+  a = nn > RSR_MINVAL ? n * frcp(nn) : v3(0, 0, 0);
   b = (a.y > -0.5f && a.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
   b = b - a * dot(a, b);
-  float bn = sqrtf(dot(b, b));
-  b = bn > RSR_MINVAL ? b * (1.0f / bn) : v3(0, 0, 0);
+  float bn = fsqrt(dot(b, b));
+  b = bn > RSR_MINVAL ? b * frcp(bn) : v3(0, 0, 0);
   c = cross(a, b);
 }
 
@@ -1369,7 +1379,7 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
       float ra = sa[i1] * AC[i2][j] + sa[i2] * AC[i1][j];
       float rb = sb[j1] * AC[i][j2] + sb[j2] * AC[i][j1];
       float tl = t[i2] * Cm[i1][j] - t[i1] * Cm[i2][j];
-      float sv = (fabsf(tl) - (ra + rb)) / sqrtf(fmaxf(l2, 1e-12f));
+      float sv = (fabsf(tl) - (ra + rb)) * frsq(fmaxf(l2, 1e-12f));
       bool ok = !(l2 < 1e-6f);
       sep |= ok && sv > 0.0f;
       if (ok && sv > best_edge) { best_edge = sv; have_edge = true; wi = i; wj = j; }
@@ -1392,12 +1402,13 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
       if (dot(Ls, dp) < 0.0f) Ls = Ls * -1.0f;
       const V3 ea_c = pa + Ai1 * ((dot(Ls, Ai1) > 0 ? 1.0f : -1.0f) * sai1) + Ai2 * ((dot(Ls, Ai2) > 0 ? 1.0f : -1.0f) * sai2);
       const V3 eb_c = pb + Bj1 * ((dot(Ls, Bj1) > 0 ? -1.0f : 1.0f) * sbj1) + Bj2 * ((dot(Ls, Bj2) > 0 ? -1.0f : 1.0f) * sbj2);
-      L = L * (1.0f / sqrtf(dot(L, L)));
+      L = L * frsq(dot(L, L));
       if (dot(L, dp) < 0.0f) L = L * -1.0f;
       V3 r = eb_c - ea_c;
       float uab = dot(eai, ebj), q1 = dot(eai, r), q2 = -dot(ebj, r), den = 1.0f - uab * uab;
-      float sp = clampf((q1 + uab * q2) / den, -ea_half, ea_half);
-      float up = clampf((uab * q1 + q2) / den, -eb_half, eb_half);
+      const float rden = frcp(den);          // (den = 1 - cos^2 of the edge pair >= 1e-6: the loop skips near-parallel edges)
+      float sp = clampf((q1 + uab * q2) * rden, -ea_half, ea_half);
+      float up = clampf((uab * q1 + q2) * rden, -eb_half, eb_half);
       V3 qa = ea_c + eai * sp, qb = eb_c + ebj * up;
       float dist = dot(qb - qa, L);
       if (!(dist < 0.0f)) return;
@@ -1472,15 +1483,15 @@ __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
   float d3 = dot(ab, bp), d4 = dot(ac, bp);
   if (d3 >= 0.0f && d4 <= d3) return b;
   float vc = d1 * d4 - d3 * d2;
-  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 / (d1 - d3));
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) return a + ab * (d1 * frcp(d1 - d3));
   V3 cp = p - c;
   float d5 = dot(ab, cp), d6 = dot(ac, cp);
   if (d6 >= 0.0f && d5 <= d6) return c;
   float vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 / (d2 - d6));
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) return a + ac * (d2 * frcp(d2 - d6));
   float va = d3 * d6 - d5 * d4;
-  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)));
-  float den = 1.0f / (va + vb + vc);
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) return b + (c - b) * ((d4 - d3) * frcp((d4 - d3) + (d5 - d6)));
+  float den = frcp(va + vb + vc);
   return a + ab * (vb * den) + ac * (vc * den);
 }
 
@@ -1495,24 +1506,25 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
   V3 p = v3(hmat[0] * rel.x + hmat[3] * rel.y + hmat[6] * rel.z, hmat[1] * rel.x + hmat[4] * rel.y + hmat[7] * rel.z,
             hmat[2] * rel.x + hmat[5] * rel.y + hmat[8] * rel.z);
   if (p.x < -sx || p.x > sx || p.y < -sy || p.y > sy) return false;
-  const float dx = 2.0f * sx / (float)(ncol - 1), dy = 2.0f * sy / (float)(nrow - 1);
-  int ci = (int)floorf((p.x + sx) / dx), ri = (int)floorf((p.y + sy) / dy);
+  const float dx = 2.0f * sx / (float)(ncol - 1), dy = 2.0f * sy / (float)(nrow - 1);      // (wave-uniform: scalar code)
+  const float rdx = frcp(dx), rdy = frcp(dy);
+  int ci = (int)floorf((p.x + sx) * rdx), ri = (int)floorf((p.y + sy) * rdy);
   ci = ci < 0 ? 0 : (ci > ncol - 2 ? ncol - 2 : ci); ri = ri < 0 ? 0 : (ri > nrow - 2 ? nrow - 2 : ri);
   V3 n, q;
   float x0 = -sx + dx * (float)ci, y0 = -sy + dy * (float)ri;
-  float u = (p.x - x0) / dx, v = (p.y - y0) / dy;
+  float u = (p.x - x0) * rdx, v = (p.y - y0) * rdy;
   float z00 = data[ri * ncol + ci] * sz, z10 = data[ri * ncol + ci + 1] * sz, z01 = data[(ri + 1) * ncol + ci] * sz, z11 = data[(ri + 1) * ncol + ci + 1] * sz;
   float gx, gy, zs;
-  if (u >= v) { gx = (z10 - z00) / dx; gy = (z11 - z10) / dy; zs = z00 + (z10 - z00) * u + (z11 - z10) * v; }
-  else { gx = (z11 - z01) / dx; gy = (z01 - z00) / dy; zs = z00 + (z11 - z01) * u + (z01 - z00) * v; }
+  if (u >= v) { gx = (z10 - z00) * rdx; gy = (z11 - z10) * rdy; zs = z00 + (z10 - z00) * u + (z11 - z10) * v; }
+  else { gx = (z11 - z01) * rdx; gy = (z01 - z00) * rdy; zs = z00 + (z11 - z01) * u + (z01 - z00) * v; }
   if (p.z < zs) {
-    float inv = 1.0f / sqrtf(gx * gx + gy * gy + 1.0f);
+    float inv = frsq(gx * gx + gy * gy + 1.0f);
     n = v3(-gx * inv, -gy * inv, inv);
     float depth = (zs - p.z) * inv;
     dist = -depth - radius;
     q = p + n * depth;
   } else {
-    int c0 = (int)floorf((p.x - radius + sx) / dx), r0 = (int)floorf((p.y - radius + sy) / dy);
+    int c0 = (int)floorf((p.x - radius + sx) * rdx), r0 = (int)floorf((p.y - radius + sy) * rdy);
     c0 = c0 < 0 ? 0 : (c0 > ncol - 3 ? ncol - 3 : c0); r0 = r0 < 0 ? 0 : (r0 > nrow - 3 ? nrow - 3 : r0);
     float best = 1e30f;
     q = p;
@@ -1529,9 +1541,9 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
         V3 db = p - qb; float d2b = dot(db, db);
         if (d2b < best) { best = d2b; q = qb; }
       }
-    float dn = sqrtf(best);
+    float dn = fsqrt(best);
     n = v3(0, 0, 1);
-    if (!(dn < 1e-12f)) n = v3((p.x - q.x) / dn, (p.y - q.y) / dn, (p.z - q.z) / dn);
+    if (!(dn < 1e-12f)) { const float rdn = frcp(dn); n = v3((p.x - q.x) * rdn, (p.y - q.y) * rdn, (p.z - q.z) * rdn); }
     dist = dn - radius;
   }
   V3 pl = q + n * (0.5f * dist);
@@ -1571,9 +1583,9 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
         const V3 n = col(R1.m, 2), axis = col(R2.m, 2);
         const float na = dot(n, axis);
         V3 b = axis - n * na;
-        const float bn = sqrtf(dot(b, b));
+        const float bn = fsqrt(dot(b, b));
         if (bn < 0.5f) b = (n.y > -0.5f && n.y < 0.5f) ? v3(0, 1, 0) : v3(0, 0, 1);
-        else b = v3(b.x / bn, b.y / bn, b.z / bn);
+        else b = b * frcp(bn);
         const float r = size2.x, hl = size2.y;
         pts.n = n; pts.t = b; pts.cnt = 2;
 #pragma unroll
@@ -1592,16 +1604,17 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
         const float r = size2.x, hl = size2.y;
         const float dist0 = dot(p2 - p1, n);
         V3 vec = axis * prjaxis - n;
-        const float len = sqrtf(dot(vec, vec));
+        const float len = fsqrt(dot(vec, vec));
         if (len < 1e-12f) vec = col(R2.m, 0) * r;
-        else vec = v3(vec.x / len * r, vec.y / len * r, vec.z / len * r);
+        else { const float rl = frcp(len); vec = v3(vec.x * rl * r, vec.y * rl * r, vec.z * rl * r); }
         const float prjvec = dot(vec, n);
         axis = axis * hl; prjaxis *= hl;
         const float prjvec1 = -prjvec * 0.5f;
         V3 vec1 = cross(vec, axis);
-        const float l1 = sqrtf(dot(vec1, vec1));
+        const float l1 = fsqrt(dot(vec1, vec1));
         const float s3 = 1.7320508075688772f;
-        vec1 = v3((l1 > 0.0f ? vec1.x / l1 : 0.0f) * r * s3 * 0.5f, (l1 > 0.0f ? vec1.y / l1 : 0.0f) * r * s3 * 0.5f, (l1 > 0.0f ? vec1.z / l1 : 0.0f) * r * s3 * 0.5f);
+        const float rl1 = l1 > 0.0f ? frcp(l1) : 0.0f;
+        vec1 = v3(vec1.x * rl1 * r * s3 * 0.5f, vec1.y * rl1 * r * s3 * 0.5f, vec1.z * rl1 * r * s3 * 0.5f);
         const float d1 = dist0 + prjaxis + prjvec, d2 = dist0 + prjaxis + prjvec1;
         pts.n = n; pts.cnt = 3;
         pts.dist[0] = d1; pts.dist[1] = d2; pts.dist[2] = d2;
@@ -1682,7 +1695,7 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
             const int pos = __popcll(b1 & below) + __popcll(b2 & below);
             if (e1) { Qn[pos] = x1; Qn[8 + pos] = y1; Qn[16 + pos] = z1; }      // (the reads were from the other buffer)
             if (e2) {
-              const float tt = d1 / (d1 - d2);
+              const float tt = d1 * frcp(d1 - d2);
               const int pi = pos + (e1 ? 1 : 0);
               Qn[pi] = x1 + tt * (x2 - x1); Qn[8 + pi] = y1 + tt * (y2 - y1); Qn[16 + pi] = z1 + tt * (z2 - z1);
             }
@@ -1873,11 +1886,11 @@ __device__ __forceinline__ void kbi(const Hot& m, float k_in, float b_in, const 
   float dmin = clampf(si[0], RSR_MINIMP, RSR_MAXIMP), dmax = clampf(si[1], RSR_MINIMP, RSR_MAXIMP);
   float width = fmaxf(si[2], RSR_MINVAL), mid = clampf(si[3], RSR_MINIMP, RSR_MAXIMP), power = fmaxf(si[4], 1.0f);
   k = k_in; b = b_in;
-  float x = fabsf(pos) / width;
+  float x = fabsf(pos) * frcp(width);
   float ia, ib;
   if (power == 2.0f) {       // MuJoCo's default; x*x is the correctly rounded square, as pow(x, 2) is
-    ia = (1.0f / mid) * (x * x);
-    ib = 1.0f - (1.0f / (1.0f - mid)) * ((1.0f - x) * (1.0f - x));
+    ia = frcp(mid) * (x * x);
+    ib = 1.0f - frcp(1.0f - mid) * ((1.0f - x) * (1.0f - x));
   } else {
     ia = (1.0f / powf(mid, power - 1.0f)) * powf(x, power);
     ib = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - x, power);
@@ -2058,14 +2071,14 @@ __device__ __forceinline__ int make_constraint(const DModel& m, const Hot& h, Sm
         float f0 = s.bmu[o.bn + 1];
         o.mu = (e & 1) ? -s.bmu[o.bk] : s.bmu[o.bk];
         float tw = asf(q1.w);
-        invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 / h.impratio;
+        invw = (tw + f0 * f0 * tw) * 2.0f * f0 * f0 * frcp(h.impratio);
         sr0 = asf(q2.x); sr1 = asf(q2.y);
         si.v[0] = asf(q2.z); si.v[1] = asf(q2.w); si.v[2] = asf(q3.x); si.v[3] = asf(q3.y); si.v[4] = asf(q3.z);
       }
       float k, b, imp;
       kbi(h, sr0, sr1, si, pos, k, b, imp);
-      float R = fmaxf(invw * (1.0f - imp) / imp, RSR_MINVAL);
-      o.R = R; o.D = 1.0f / R; o.floss = fl;
+      float R = fmaxf(invw * (1.0f - imp) * frcp(imp), RSR_MINVAL);
+      o.R = R; o.D = frcp(R); o.floss = fl;
       o.aref = -k * imp * pos;        // the caller subtracts b * (J.qvel)
       rr[ch] = o;
       bcoef[ch] = b;

@@ -1339,7 +1339,10 @@ __global__ __launch_bounds__(64) void hs_reset_kernel(const DModel* __restrict__
 
 // handstand.py:161-195 with the rewards :264-342, + wrappers
 template <class C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef RSR_HS_WAVES_PER_EU
+#define RSR_HS_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSR_HS_WAVES_PER_EU, RSR_HS_WAVES_PER_EU)))
 void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   const DModel& m = *mp;
   const Hot hot = make_hot(m);

@@ -629,6 +629,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     PROF(PS_UPD)
     ++iter;
   }
+  PROF(PS_U_JTF)
   st.niter = iter; st.ls_total = ls_total;
   qacc_out = qacc; qfc_out = qfc;
 }
@@ -773,6 +774,7 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
     qacc = lane < C::NV ? chol_solve<C>(a, lt, dinv_i, f.fsmooth + f.qfc, lane) : 0.0f;
     }
   }
+  PROF(PS_X7)
   WSYNC();
   if (lane < C::NV) s.qvel[lane] += qacc * m.timestep;
   WSYNC();
@@ -782,14 +784,14 @@ __device__ __forceinline__ void integrate(const DModel& mdl, const Hot& h, Smem<
     if (rj_ids.z == JNT_FREE) {
       s.qpos[qa] += dt * s.qvel[da]; s.qpos[qa + 1] += dt * s.qvel[da + 1]; s.qpos[qa + 2] += dt * s.qvel[da + 2];
       V3 w = ld3(&s.qvel[da + 3]);
-      float n = sqrtf(dot(w, w));
-      V3 ax = n > RSR_MINVAL ? w * (1.0f / n) : v3(0, 0, 0);
+      float n = fsqrt(dot(w, w));
+      V3 ax = n > RSR_MINVAL ? w * frcp(n) : v3(0, 0, 0);
       float sn, cs;
       sincosf(0.5f * dt * n, &sn, &cs);
       Q4 q = qmul(ld4(&s.qpos[qa + 3]), Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
-      float qn = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+      float qn = fsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
       if (qn < RSR_MINVAL) q = Q4{1, 0, 0, 0};
-      else { float inv = 1.0f / qn; q = Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv}; }
+      else { float inv = frcp(qn); q = Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv}; }
       st4(&s.qpos[qa + 3], q);
     } else {
       s.qpos[qa] += dt * s.qvel[da];
