@@ -1,6 +1,6 @@
 """Bit-for-bit comparison of two builds of the library on rollouts of the four workloads (an optimisation that reorders no
-arithmetic must not move a bit): python tools/gpu_bitcompare.py libA.so libB.so [--workloads cube,tshape,go2,go2rough] [--steps 40]
-Each build runs in its own process (the library path is read once per process) and dumps the records after the rollout."""
+arithmetic must not move a bit): python tools/gpu_bitcompare.py libA.so libB.so[@VAR=val,...] [--workloads cube,tshape,go2,go2rough,handstand] [--steps 40]
+(`@VAR=val` sets environment variables for that arm, e.g. RSR_WHOLE_ENVS=0 RSR_UNITS=5: the same build under another schedule.)  Each build runs in its own process (the library path is read once per process) and dumps the records after the rollout."""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +20,7 @@ def child(workloads, steps, out):
             nu, astd = 5, 1.0
         else:
             from rsr_mjx_amd.envs import go2
-            jenv = go2.load("Go2JoystickRoughTerrain" if wl == "go2rough" else "Go2JoystickFlatTerrain")
+            jenv = go2.load("Go2Handstand" if wl == "handstand" else ("Go2JoystickRoughTerrain" if wl == "go2rough" else "Go2JoystickFlatTerrain"))
             dr = go2.domain_randomize(jenv.sys, prng.split(prng.PRNGKey(12), n))
             env = go2.wrap_for_brax_training(jenv, n, episode_length=25, randomization_fn=lambda sys: dr)
             nu, astd = 12, 0.5
@@ -42,11 +42,14 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     wls = args[args.index("--workloads") + 1] if "--workloads" in args else "cube,tshape,go2,go2rough"
     steps = args[args.index("--steps") + 1] if "--steps" in args else "40"
-    libs = [a for a in args if a.endswith(".so")]
+    libs = [a for a in args if a.partition("@")[0].endswith(".so")]
     outs = []
     for lib in libs:
         out = tempfile.mktemp(suffix=".npz")
-        env = dict(os.environ, RSR_MJX_LIB=os.path.join(ROOT, "rsr_mjx_amd", "csrc", lib))
+        name, _, kvs = lib.partition("@")
+        env = dict(os.environ, RSR_MJX_LIB=os.path.join(ROOT, "rsr_mjx_amd", "csrc", name))
+        for kv in filter(None, kvs.split(",")):
+            k, _, v = kv.partition("="); env[k] = v
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", wls, steps, out], env=env)
         outs.append(np.load(out))
     ok = True
