@@ -329,7 +329,7 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 // Newton step for the reciprocals -- 3-4 instructions -- instead of the IEEE expansions of `/` and sqrtf() (v_div_scale x 2, v_rcp,
 // four fma, v_div_fmas, v_div_fixup: 10-11 dependent instructions per division, ~45 divisions per substep of the cube model).
 // Results are within ~1 ulp of the correctly rounded ones: the same order as the fma contraction the kernels already differ from the
-// oracle by.  The env algebra (prologue, rewards, observations: the reference's op-by-op JAX-CPU arithmetic) and the solver's norms keep `/` and sqrtf().
+// oracle by.  The env algebra (prologue, rewards, observations: the reference's op-by-op JAX-CPU arithmetic) keeps `/` and sqrtf().
 // Arguments: finite, non-zero (frcp, frsq: > 0); fsqrt: >= 0, and values below the normal range count as zero (every caller tests
 // its norm against RSR_MINVAL or adds a floor).
 __device__ __forceinline__ float frcp(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r); }

@@ -484,7 +484,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   while (true) {
     bool done;
     if (opt_iterations != 1) {
-      float gn = sqrtf(wave_sum(grad * grad));
+      float gn = fsqrt(wave_sum(grad * grad));
       done = iter >= opt_iterations;
       done |= scale * (prev_cost - cost) < opt_tolerance;
       done |= scale * gn < opt_tolerance;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     jdot<C>(s, lane, nefc, nbase, rr, sb, jv);
     float snorm = search * search, g1a = search * Ma, g1b = search * fs;
     wave_sum3(snorm, g1a, g1b);
-    snorm = sqrtf(snorm);
+    snorm = fsqrt(snorm);
     float gtol = opt_tolerance * opt_ls_tolerance * snorm * opt_meaninertia * (float)(C::NV > 1 ? C::NV : 1);
     float g1 = g1a - g1b;
     // fp32 noise floor of the 1-D derivative: d0(alpha) = 2 alpha q2 + q1 is a sum of up to NEFC terms, so values
