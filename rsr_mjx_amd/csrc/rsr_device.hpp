@@ -1241,54 +1241,7 @@ __device__ __forceinline__ void make_frame(V3 n, V3& a, V3& b, V3& c) {
   c = cross(a, b);
 }
 
-// choose <=4 of n masked 2-D points with approximately maximal area; see oracle manifold_points
-__device__ __forceinline__ void manifold_points(const float* x, const float* y, unsigned mask, int n, int* idx) {
-  // The (at most 8) points are fetched once, all loads in flight together, and every pass runs over registers with
-  // compile-time indices; the chosen point's coordinates are carried along with its index (a runtime index into the
-  // register copy would send it to scratch memory, and four passes over LDS are 4n dependent round trips).
-  const float NEG = -1e6f;
-  float px[8], py[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { px[i] = x[i]; py[i] = y[i]; }      // slots >= n hold stale data: masked by i < n below
-  int a = 0, b = 0, c = 0, dd = 0;
-  float xa = 0, ya = 0, xb = 0, yb = 0, xc = 0, yc = 0;
-  float best = NEG * 2;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float v = ((mask >> i) & 1) ? 0.0f : NEG;
-    if (i < n && v > best) { best = v; a = i; xa = px[i]; ya = py[i]; }
-  }
-  best = NEG * 4;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float dx = xa - px[i], dy = ya - py[i];
-    float v = dx * dx + dy * dy + (((mask >> i) & 1) ? 0.0f : NEG);
-    if (i < n && v > best) { best = v; b = i; xb = px[i]; yb = py[i]; }
-  }
-  float abx = -(ya - yb), aby = (xa - xb);
-  best = NEG * 4;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float v = fabsf((xa - px[i]) * abx + (ya - py[i]) * aby) + (((mask >> i) & 1) ? 0.0f : NEG);
-    if (i < n && v > best) { best = v; c = i; xc = px[i]; yc = py[i]; }
-  }
-  float sc = ((xa - xc) * abx + (ya - yc) * aby) > 0 ? 1.0f : -1.0f;
-  best = 0; dd = c;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float v = -sc * ((xa - px[i]) * abx + (ya - py[i]) * aby);
-    if (i < n && ((mask >> i) & 1) && v > best) { best = v; dd = i; }
-  }
-  idx[0] = a; idx[1] = b; idx[2] = c; idx[3] = dd;
-}
-
 struct CPts { float dist[4]; V3 pos[4]; V3 n; int cnt; V3 t; };      // t: first tangent of the frame (Dims::CAPS), zero = default
-// append without a runtime array index (a runtime index would put the whole struct in scratch memory)
-__device__ __forceinline__ void cpts_push(CPts& o, float dist, V3 pos) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) if (o.cnt == k) { o.dist[k] = dist; o.pos[k] = pos; }
-  o.cnt++;
-}
 
 // A pair whose narrow phase found penetration and now needs LDS scratch for its manifold (24 floats for
 // plane-box vertex supports, 48 for the two ping-pong polygons of box-box clipping).  Everything the second
@@ -1319,24 +1272,6 @@ __device__ __forceinline__ void plane_box_sat(V3 pp, const float* pm, V3 bp, con
   job.kind = 1; job.o = pp; job.nref = n; job.axu = col(pm, 0); job.axv = col(pm, 1);
   job.bp = bp; job.size = size; job.bm = bm_lds; job.hu = smax;
 }
-// The owner lane's part of a plane-box manifold: supports and in-plane coordinates of the eight vertices are in scr (written
-// one vertex per lane by collision()); vertices within 1 mm of the deepest, <= 4 of them by manifold_points.
-__device__ void plane_box_finish(const ClipJob& job, const float* scr, CPts& out) {
-  const float* sup = scr; const float* vx = scr + 8; const float* vy = scr + 16;
-  float thr = fmaxf(job.hu - 1e-3f, 0.0f);
-  unsigned mask = 0;
-  for (int v = 0; v < 8; ++v) if (sup[v] > thr) mask |= 1u << v;
-  int idx[4];
-  manifold_points(vx, vy, mask, 8, idx);
-  for (int i = 0; i < 4; ++i) {
-    bool dup = false;
-    for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
-    if (dup || !((mask >> idx[i]) & 1)) continue;
-    float dist = -sup[idx[i]];
-    cpts_push(out, dist, box_vertex(job.bm, job.bp, job.size, idx[i]) - job.nref * (0.5f * dist));
-  }
-}
-
 // 15-axis SAT.  Separated pairs return nothing; edge-edge contacts are finished here; face contacts fill `job`.
 __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 pb, const float* Rb, V3 sb_, CPts& out, ClipJob& job) {
   out.cnt = 0; job.kind = 0;
@@ -1455,24 +1390,6 @@ __device__ __forceinline__ void box_box_sat(V3 pa, const float* Ra, V3 sa_, V3 p
   job.kind = 2; job.o = o; job.nref = nref; job.axu = axu; job.axv = axv; job.hu = hu; job.hv = hv; job.flip = !ref_is_a;
 }
 
-// The owner lane's part of a box-box face manifold: P = the incident face clipped against the reference rectangle (np points:
-// x[8], y[8], depth[8], written by collision()'s four lane-per-vertex passes); <= 4 penetrating points by manifold_points.
-__device__ void box_box_finish(const ClipJob& job, const float* P, int np, CPts& out) {
-  if (np == 0) return;
-  unsigned mask = 0;
-  for (int i = 0; i < np; ++i) if (P[16 + i] > 0.0f) mask |= 1u << i;
-  if (!mask) return;
-  int idx[4];
-  manifold_points(P, P + 8, mask, np, idx);
-  out.n = job.flip ? job.nref * -1.0f : job.nref;
-  for (int i = 0; i < 4; ++i) {
-    bool dup = false;
-    for (int j = 0; j < i; ++j) dup |= (idx[j] == idx[i]);
-    if (dup || !((mask >> idx[i]) & 1)) continue;
-    float x = P[idx[i]], y = P[8 + idx[i]], dep = P[16 + idx[i]];
-    cpts_push(out, -dep, job.o + job.axu * x + job.axv * y - job.nref * (0.5f * dep));
-  }
-}
 
 // closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5)
 __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
@@ -1657,8 +1574,10 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
 #pragma unroll
           for (int c = 0; c < 9; ++c) q[6 + c] = job.bm[c];
           st3(q + 15, job.o); st3(q + 18, job.nref); st3(q + 21, job.axu); st3(q + 24, job.axv);
+          q[27] = job.hu;
         } else {
           q[0] = job.hu; q[1] = job.hv;
+          st3(q + 15, job.o); st3(q + 18, job.nref); st3(q + 21, job.axu); st3(q + 24, job.axv);
           float* P0 = poly + rank * 48;
 #pragma unroll
           for (int i = 0; i < 4; ++i) { P0[i] = job.px[i]; P0[8 + i] = job.py[i]; P0[16 + i] = job.pd[i]; }
@@ -1671,10 +1590,15 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
         const float* q = par + slot * 32;
         const int kind = slot < nslots ? (int)q[31] : 0;
         float* P = poly + slot * 48;
+        // this lane's point of its pair's candidate set: in-plane coordinates (mx, my) and the third value (plane-box: support of
+        // the vertex; box-box: depth of the clipped polygon's vertex), and where it would put a contact (cw: the box vertex itself)
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        V3 cw = v3(0, 0, 0);
+        const V3 jo = ld3(q + 15), jn = ld3(q + 18), jau = ld3(q + 21), jav = ld3(q + 24);      // (kind 0: stale words, unused)
         if (kind == 1) {                                     // plane-box: vertex v's support and in-plane coordinates
-          V3 bp = ld3(q), size = ld3(q + 3), o = ld3(q + 15), nref = ld3(q + 18), axu = ld3(q + 21), axv = ld3(q + 24);
-          V3 w = box_vertex(q + 6, bp, size, v);
-          P[v] = dot(o - w, nref); P[8 + v] = dot(w, axu); P[16 + v] = dot(w, axv);
+          V3 bp = ld3(q), size = ld3(q + 3);
+          cw = box_vertex(q + 6, bp, size, v);
+          mz = dot(jo - cw, jn); mx = dot(cw, jau); my = dot(cw, jav);
         }
         // box-box: four clipping passes against the reference rectangle
         const bool bb = kind == 2;
@@ -1703,14 +1627,77 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
             cur = 1 - cur;
             WSYNC();
           }
-          if (bb && v == 0) par[slot * 32 + 30] = (float)np;
+          if (bb && v < np) { mx = P[v]; my = P[8 + v]; mz = P[16 + v]; }      // four passes: the result is back in the first buffer
         }
+        // ---- the <= 4-point manifold (oracle manifold_points: first candidate, farthest from it, farthest from their line, farthest
+        // on the other side), one lane per candidate: a pass is one value per lane and an arg-max over the pair's eight lanes (three
+        // DPP steps on (value, index), the first maximum wins as in the serial scan) instead of a scan over eight register copies
+        // by the pair's owner lane, once per kind of pair present.  Same arithmetic per candidate, same picks.
+        const int n = kind == 1 ? 8 : np;
+        const bool valid = v < n;
+        const bool on = valid && (kind == 1 ? mz > fmaxf(q[27] - 1e-3f, 0.0f) : mz > 0.0f);
+        const unsigned gm = (unsigned)(__ballot(on) >> (8 * slot)) & 0xFFu;
+        const int g0 = lane & ~7;
+        const float NEG = -1e6f, pen = on ? 0.0f : NEG;
+        auto argmax8 = [&](float val, int& wi) {          // -> index of the first maximum of val over the group's valid lanes
+          float bv = valid ? val : -3.0e38f; int bi = v;
+#pragma unroll
+          for (int st = 0; st < 3; ++st) {
+            float ov; int oi;
+            if (st == 0) { ov = dpp_mov<0xB1>(bv); oi = __builtin_bit_cast(int, dpp_mov<0xB1>(__builtin_bit_cast(float, bi))); }
+            else if (st == 1) { ov = dpp_mov<0x4E>(bv); oi = __builtin_bit_cast(int, dpp_mov<0x4E>(__builtin_bit_cast(float, bi))); }
+            else { ov = dpp_mov<0x141>(bv); oi = __builtin_bit_cast(int, dpp_mov<0x141>(__builtin_bit_cast(float, bi))); }
+            const bool take = ov > bv || (ov == bv && oi < bi);
+            bv = take ? ov : bv; bi = take ? oi : bi;
+          }
+          wi = bi;
+          return bv;
+        };
+        const int ia = gm ? __builtin_ctz(gm) : 0;
+        const float xa = __shfl(mx, g0 + ia), ya = __shfl(my, g0 + ia);
+        int ib, ic, id;
+        {
+          const float dx = xa - mx, dy = ya - my;
+          argmax8(dx * dx + dy * dy + pen, ib);
+        }
+        const float xb = __shfl(mx, g0 + ib), yb = __shfl(my, g0 + ib);
+        const float abx = -(ya - yb), aby = (xa - xb);
+        const float crs = (xa - mx) * abx + (ya - my) * aby;
+        argmax8(fabsf(crs) + pen, ic);
+        const float crs_c = __shfl(crs, g0 + ic);
+        const float sgn = crs_c > 0 ? 1.0f : -1.0f;
+        {
+          const float best = argmax8(on ? -sgn * crs : -1.0f, id);
+          if (!(best > 0.0f)) id = ic;
+        }
+        // contacts in the order a, b, c, d without repeats (a, b, c are candidates by construction; the checks are the oracle's)
+        const bool use_b = ib != ia && ((gm >> ib) & 1u), use_c = ic != ia && ic != ib && ((gm >> ic) & 1u);
+        const bool use_d = id != ia && id != ib && id != ic && ((gm >> id) & 1u);
+        const int cnt = gm ? 1 + (use_b ? 1 : 0) + (use_c ? 1 : 0) + (use_d ? 1 : 0) : 0;
+        int k = -1;
+        if (gm && v == ia) k = 0;
+        else if (use_b && v == ib) k = 1;
+        else if (use_c && v == ic) k = 1 + (use_b ? 1 : 0);
+        else if (use_d && v == id) k = 1 + (use_b ? 1 : 0) + (use_c ? 1 : 0);
+        float* const R = P + 24;                             // the second polygon buffer: [4][4] = dist, pos
+        if (kind != 0 && k >= 0) {
+          const float dist = -mz;
+          const V3 cp = kind == 1 ? cw - jn * (0.5f * dist) : jo + jau * mx + jav * my - jn * (0.5f * mz);
+          R[4 * k] = dist; st3(&R[4 * k + 1], cp);
+        }
+        if (kind != 0 && v == 0) par[slot * 32 + 30] = (float)cnt;
       }
       WSYNC();
       if (mine) {
-        float* scr = poly + rank * 48;
-        if (job.kind == 1) plane_box_finish(job, scr, pts);
-        else box_box_finish(job, scr, (int)par[rank * 32 + 30], pts);      // four passes: the result is back in the first buffer
+        const float* R = poly + rank * 48 + 24;
+        const int cnt = (int)par[rank * 32 + 30];
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = R[i];
+        if (job.kind == 2) pts.n = job.flip ? job.nref * -1.0f : job.nref;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pts.dist[i] = r[4 * i]; pts.pos[i] = V3{r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]}; }
+        pts.cnt = cnt;
         job.kind = 0;
       }
       WSYNC();

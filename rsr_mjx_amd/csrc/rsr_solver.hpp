@@ -296,7 +296,7 @@ __device__ __forceinline__ float hessian_factor(Smem<C>& s, int lane, int nefc, 
   // instead of a counting loop of up to NBLK trips per Hessian)
   int bi = 0;
   if constexpr (C::ROWCHOL) {        // (measured: +0.9 % on the cube; the Go2 kernel is 2 % faster with the loop)
-    bi = (int)((__builtin_sqrtf(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);
+    bi = (int)((fsqrt(8.0f * (float)lane + 1.0f) - 1.0f) * 0.5f);      // (1 ulp is enough: the two fix-ups below)
     bi += ((bi + 1) * (bi + 2) / 2 <= lane) ? 1 : 0;
     bi -= (bi * (bi + 1) / 2 > lane) ? 1 : 0;
   } else {
