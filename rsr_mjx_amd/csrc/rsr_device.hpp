@@ -1265,9 +1265,9 @@ __device__ __forceinline__ V3 box_vertex(const float* bm, V3 bp, V3 size, int v)
 __device__ __forceinline__ void plane_box_sat(V3 pp, const float* pm, V3 bp, const float* bm, const float* bm_lds, V3 size, CPts& out, ClipJob& job) {
   V3 n = col(pm, 2);
   out.n = n; out.cnt = 0; job.kind = 0;
-  float smax = -1e30f;
-#pragma unroll
-  for (int v = 0; v < 8; ++v) smax = fmaxf(smax, dot(pp - box_vertex(bm, bp, size, v), n));
+  // deepest vertex's penetration in closed form: the support of the box along -n (the eight vertices evaluated one by one were ~100
+  // instructions per substep; the candidates' own supports are evaluated per vertex, one lane each, in collision())
+  const float smax = dot(pp - bp, n) + fabsf(dot(col(bm, 0), n) * size.x) + fabsf(dot(col(bm, 1), n) * size.y) + fabsf(dot(col(bm, 2), n) * size.z);
   if (!(smax > 0.0f)) return;
   job.kind = 1; job.o = pp; job.nref = n; job.axu = col(pm, 0); job.axv = col(pm, 1);
   job.bp = bp; job.size = size; job.bm = bm_lds; job.hu = smax;
