@@ -481,10 +481,13 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
   bool have_factor = false;
 #pragma unroll
   for (int ch = 0; ch < C::NCHUNK; ++ch) hw_fact[ch] = 0.0f;
+  // |grad|^2: summed here for the first exit test, afterwards in the same reduction as the cost of the new point (one reduction per
+  // Newton iteration less; the chains of a three-value reduction pair their additions as a single one does: same bits)
+  float gn2 = opt_iterations != 1 ? wave_sum(grad * grad) : 0.0f;
   while (true) {
     bool done;
     if (opt_iterations != 1) {
-      float gn = fsqrt(wave_sum(grad * grad));
+      float gn = fsqrt(gn2);
       done = iter >= opt_iterations;
       done |= scale * (prev_cost - cost) < opt_tolerance;
       done |= scale * gn < opt_tolerance;
@@ -618,14 +621,14 @@ __device__ __forceinline__ void solve(const Hot& m, Smem<C>& s, int lane, int ne
     // ---------------- update constraint + gradient ----------------
     rc = rows_cost<C, false>(lane, nefc, jaref, rr, force, hw);
     gauss = dofl ? (Ma - fs) * (qacc - a0) : 0.0f;
-    unused = 0.0f;
-    wave_sum3(rc, gauss, unused);
-    gauss *= 0.5f;
-    prev_cost = cost; cost = rc + gauss;
-    if (dbg && lane == 0 && iter < 16) { dbg[7410 + 4 * iter] = cost; dbg[7411 + 4 * iter] = improved ? alpha : 0.0f; dbg[7412 + 4 * iter] = (float)it; dbg[7413 + 4 * iter] = p0_d0; }
     PROF(PS_X6)
     qfc = jt_force<C>(s, lane, nefc, nbase, force);
     grad = dofl ? Ma - fs - qfc : 0.0f;
+    gn2 = grad * grad;
+    wave_sum3(rc, gauss, gn2);
+    gauss *= 0.5f;
+    prev_cost = cost; cost = rc + gauss;
+    if (dbg && lane == 0 && iter < 16) { dbg[7410 + 4 * iter] = cost; dbg[7411 + 4 * iter] = improved ? alpha : 0.0f; dbg[7412 + 4 * iter] = (float)it; dbg[7413 + 4 * iter] = p0_d0; }
     PROF(PS_UPD)
     ++iter;
   }

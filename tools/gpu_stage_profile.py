@@ -18,7 +18,7 @@ NAMES = ["load", "kinematics", "com_crb_mass", "collision", "constraint_rows", "
          "solver_init", "hessian: solve only", "linesearch: p0, lo, iterations", "update_constraint", "integrate", "epilogue+store",
          "hessian: weights+compaction", "hessian: sparse rows", "hessian: contacts", "hessian: block exchange", "hessian: cholesky",
          "linesearch: setup (jdot, M.v, sums)", "x0 collision: SAT / primitives", "x1 collision: clip slots", "x2 collision: compaction",
-         "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: cost + gauss (rest of update = J^T f)", "integrate: factor of M + h D, solve (rest of integrate = advance)",
+         "x3 rows: limits, zeroing, sparse", "x4 rows: contact base rows", "x5 rows: friction coefficients", "x6 update: row forces and costs of the new point (rest of update = J^T f, gradient, the sums)", "integrate: factor of M + h D, solve (rest of integrate = advance)",
          "ls: prepare (row pieces)", "ls: point alpha=0", "ls: first Newton point", "ls: iterations", "solver exit: final costs and step of a one-iteration solve, exit test", "init: M.a, J.a, costs of both starts", "init: J^T f, gradient",
          "kin: record loads", "kin: local transforms (sincos)", "kin: tree composition", "kin: body stores + barrier",
          "crb: record loads", "crb: subtree com", "crb: cinert, cdof, M zero", "crb: composite inertia",
