@@ -1870,10 +1870,10 @@ struct Solimp { float v[5]; };
 // model.stiffness_damping() exactly as this function computed them per row and substep)
 __device__ __forceinline__ void kbi(const Hot& m, float k_in, float b_in, const Solimp& sip, float pos, float& k, float& b, float& imp) {
   const float* si = sip.v;
-  float dmin = clampf(si[0], RSR_MINIMP, RSR_MAXIMP), dmax = clampf(si[1], RSR_MINIMP, RSR_MAXIMP);
-  float width = fmaxf(si[2], RSR_MINVAL), mid = clampf(si[3], RSR_MINIMP, RSR_MAXIMP), power = fmaxf(si[4], 1.0f);
+  // (d0, d_width, 1 / width, midpoint, power), clamped on the host: model.impedance_consts()
+  const float dmin = si[0], dmax = si[1], rwidth = si[2], mid = si[3], power = si[4];
   k = k_in; b = b_in;
-  float x = fabsf(pos) * frcp(width);
+  float x = fabsf(pos) * rwidth;
   float ia, ib;
   if (power == 2.0f) {       // MuJoCo's default; x*x is the correctly rounded square, as pow(x, 2) is
     ia = frcp(mid) * (x * x);

@@ -167,6 +167,16 @@ def stiffness_damping(solref, solimp, timestep, disable_refsafe) -> tuple:
     return f(k), f(b)
 
 
+def impedance_consts(solimp) -> np.ndarray:
+    """solimp as the kernel's impedance function consumes it: (d0, d_width, 1 / width, midpoint, power) with MuJoCo's clamps applied
+    (getimpedance: d in [mjMINIMP, mjMAXIMP], width >= mjMINVAL, power >= 1) -- model constants, so the host clamps and takes the
+    reciprocal once, in float32, instead of every row of every substep."""
+    f = np.float32
+    clampi = lambda x: min(max(f(x), f(0.0001)), f(0.9999))
+    width = max(f(solimp[2]), f(1e-15))
+    return np.array([clampi(solimp[0]), clampi(solimp[1]), f(1.0) / width, clampi(solimp[3]), max(f(solimp[4]), f(1.0))], dtype=np.float32)
+
+
 def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=None) -> np.ndarray:
     """Per-lane constant records for the tree stages of the kernel: int32 [LANE_QUADS][64][4] (floats stored by bit pattern).
 
@@ -185,7 +195,7 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
              21 (biasprm1, biasprm2, i forcelimited, force lo)  22 (force hi, i actfrclimited, actfrc lo, actfrc hi)
     and, indexed by the constraint-side roles (friction row l, limit slot l, geom pair l, equality l):
       (every `solref 0 1` below is stored as the row's stiffness / damping (k, b): stiffness_damping())
-      fric : 23 (i dof, invweight0, solref 0 1)  24 (solimp 0..3)  25 (solimp 4, 0, 0, 0)
+      fric : 23 (i dof, invweight0, solref 0 1)  24 (solimp 0..3)  25 (solimp 4, 0, 0, 0)      [solimp: as impedance_consts() returns it]
       limit: 26 (i qposadr, i dofadr, range lo hi)  27 (margin, invweight0, solref 0 1)  28 (solimp 0..3)  29 (solimp 4, i joint, 0, 0)
       pair : 30 (i slot of geom1, i slot of geom2, i kind, margin - gap)  31 (size[geom1] xyz, tw)  32 (size[geom2] xyz, i friction rule: 0 max,
              1 geom1's, 2 geom2's)  33 (i mask1, i mask2, i root1, i root2)  34 (solref 0 1, solimp 0 1)  35 (solimp 2 3 4, 0)
@@ -253,15 +263,17 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
         i = int(i)
         rec[23, l, 0] = i
         fv[23, l, 1:] = [A["dof_invweight0"][i], *kb(A["dof_solref"][i], A["dof_solimp"][i])]
-        fv[24, l] = A["dof_solimp"][i][:4]
-        fv[25, l, 0] = A["dof_solimp"][i][4]
+        si = impedance_consts(A["dof_solimp"][i])
+        fv[24, l] = si[:4]
+        fv[25, l, 0] = si[4]
     for l, j in enumerate(topo["limit_jnts"]):
         j = int(j)
         rec[26, l, :2] = [A["jnt_qposadr"][j], A["jnt_dofadr"][j]]
         fv[26, l, 2:] = A["jnt_range"][j]
         fv[27, l] = [A["jnt_margin"][j], A["dof_invweight0"][int(A["jnt_dofadr"][j])], *kb(A["jnt_solref"][j], A["jnt_solimp"][j])]
-        fv[28, l] = A["jnt_solimp"][j][:4]
-        fv[29, l, 0] = A["jnt_solimp"][j][4]
+        si = impedance_consts(A["jnt_solimp"][j])
+        fv[28, l] = si[:4]
+        fv[29, l, 0] = si[4]
         rec[29, l, 1] = j
     for q in range(m.npair):
         g1, g2 = int(A["pair_geom1"][q]), int(A["pair_geom2"][q])
@@ -272,8 +284,9 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
         p1, p2 = int(A["geom_priority"][g1]), int(A["geom_priority"][g2])
         rec[32, q, 3] = 0 if p1 == p2 else (1 if p1 > p2 else 2)
         rec[33, q] = [topo["pair_mask1"][q], topo["pair_mask2"][q], topo["pair_root1"][q], topo["pair_root2"][q]]
-        fv[34, q] = [*kb(A["pair_solref"][q], A["pair_solimp"][q]), *A["pair_solimp"][q][:2]]
-        fv[35, q, :3] = A["pair_solimp"][q][2:5]
+        si = impedance_consts(A["pair_solimp"][q])
+        fv[34, q] = [*kb(A["pair_solref"][q], A["pair_solimp"][q]), *si[:2]]
+        fv[35, q, :3] = si[2:5]
     for e in range(int(A["eq_obj1id"].shape[0])):
         j1, j2 = int(A["eq_obj1id"][e]), int(A["eq_obj2id"][e])
         d1 = int(A["jnt_dofadr"][j1])
@@ -285,8 +298,9 @@ def lane_records(m: CompiledModel, topo: Dict[str, np.ndarray], geom_slot_ids=No
             rec[37, e, :3] = [1, A["jnt_qposadr"][j2], d2]
         fv[36, e, 3] = invw
         fv[38, e] = A["eq_data"][e][:4]
-        fv[39, e] = [A["eq_data"][e][4], *kb(A["eq_solref"][e], A["eq_solimp"][e]), A["eq_solimp"][e][0]]
-        fv[40, e] = A["eq_solimp"][e][1:5]
+        si = impedance_consts(A["eq_solimp"][e])
+        fv[39, e] = [A["eq_data"][e][4], *kb(A["eq_solref"][e], A["eq_solimp"][e]), si[0]]
+        fv[40, e] = si[1:5]
     return rec
 
 

@@ -75,6 +75,7 @@ def test_lane_records_restate_the_model_tables(cube_model):
     (layout documented in lane_records; the device side is enum LaneQuad in csrc/rsr_device.hpp, whose count the library
     checks against the blob at rsr_model_create)."""
     import re
+    from rsr_mjx_amd import model as M
     from rsr_mjx_amd.model import LANE_QUADS, lane_records, topology_tables
     m = cube_model
     A, topo = m.arrays, topology_tables(m)
@@ -102,14 +103,17 @@ def test_lane_records_restate_the_model_tables(cube_model):
     for l, j in enumerate(topo["limit_jnts"]):
         assert list(rec[26, l, :2]) == [A["jnt_qposadr"][j], A["jnt_dofadr"][j]] and rec[29, l, 1] == j
         np.testing.assert_array_equal(fv[26, l, 2:], f32(A["jnt_range"][j]))
-        np.testing.assert_array_equal([*fv[28, l], fv[29, l, 0]], f32(A["jnt_solimp"][j]))
+        np.testing.assert_array_equal([*fv[28, l], fv[29, l, 0]], M.impedance_consts(A["jnt_solimp"][j]))
     for q in range(m.npair):
         g1, g2 = int(A["pair_geom1"][q]), int(A["pair_geom2"][q])
         assert list(rec[30, q, :3]) == [g1, g2, A["pair_kind"][q]]
         np.testing.assert_array_equal(fv[32, q, :3], f32(A["geom_size"][g2]))
         p1, p2 = A["geom_priority"][g1], A["geom_priority"][g2]
         assert rec[32, q, 3] == (0 if p1 == p2 else (1 if p1 > p2 else 2))
-        np.testing.assert_array_equal([*fv[34, q, 2:], *fv[35, q, :3]], f32(A["pair_solimp"][q]))
+        np.testing.assert_array_equal([*fv[34, q, 2:], *fv[35, q, :3]], M.impedance_consts(A["pair_solimp"][q]))
+    # (solimp travels as the impedance function consumes it: MuJoCo's clamps applied, the width as its reciprocal)
+    np.testing.assert_array_equal(M.impedance_consts([0.9, 0.95, 0.001, 0.5, 2.0]), f32([0.9, 0.95, np.float32(1.0) / np.float32(0.001), 0.5, 2.0]))
+    np.testing.assert_array_equal(M.impedance_consts([0.0, 1.5, 0.0, 2.0, 0.5]), f32([0.0001, 0.9999, np.float32(1.0) / np.float32(1e-15), 0.9999, 1.0]))
     # the rows' stiffness / damping (k, b) stand where solref stood: SURVEY B.10's formulas in double, to float32 rounding
     dt = float(A["opt_timestep"][0])
     def kb64(solref, solimp):
