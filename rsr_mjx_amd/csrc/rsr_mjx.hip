@@ -1645,7 +1645,8 @@ extern "C" const char* rsr_last_error(void) { return g_err.c_str(); }
 extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out) {
   if (!blob || !out || nbytes < 32) return fail(RSR_ERR_ARG, "rsr_model_create: null or short blob");
   const int32_t* h = static_cast<const int32_t*>(blob);
-  if (std::memcmp(blob, "RSRM", 4) != 0 || h[1] != 1 || (size_t)h[3] > nbytes) return fail(RSR_ERR_ARG, "rsr_model_create: not an RSRM v1 blob");
+  if (std::memcmp(blob, "RSRM", 4) != 0 || h[1] != 2 || (size_t)h[3] > nbytes)
+    return fail(RSR_ERR_ARG, "rsr_model_create: not an RSRM v2 blob (v2: the lane records carry solimp clamped and with 1 / width: rsr_mjx_amd/model.py impedance_consts)");
   {  // every directory entry must lie inside the blob before anything is read through it (header: magic, version, entry count, bytes)
     const long long nent = h[2];
     if (nent < 0 || 16 + (unsigned long long)nent * sizeof(blob_entry) > nbytes) return fail(RSR_ERR_ARG, "rsr_model_create: entry table exceeds the blob");

@@ -21,7 +21,7 @@ import numpy as np
 from .mjcf import CompiledModel
 
 MAGIC = b"RSRM"
-VERSION = 1
+VERSION = 2            # 2: lane records carry solimp as impedance_consts() returns it (the kernels do not clamp it again)
 _NAME_LEN = 40
 _ENTRY = struct.Struct(f"<{_NAME_LEN}siiii")
 _HEADER = struct.Struct("<4siii")
@@ -61,7 +61,7 @@ def pack_blob(fields: Dict[str, np.ndarray]) -> bytes:
 def unpack_blob(blob: bytes) -> Dict[str, np.ndarray]:
     magic, ver, n, total = _HEADER.unpack_from(blob, 0)
     if magic != MAGIC or ver != VERSION:
-        raise ValueError("not an RSRM v1 blob")
+        raise ValueError(f"not an RSRM v{VERSION} blob")
     out = {}
     for i in range(n):
         name, dt, cnt, off, _ = _ENTRY.unpack_from(blob, _HEADER.size + i * _ENTRY.size)
