@@ -76,7 +76,7 @@ for k,v in sorted(byline.items(), key=lambda x:-x[1])[:40]: print(k,v)
 print('--- program order (every 250 instr): idx line live')
 for i in range(0,n,250): print(i, ins[i][3], len(live_in[i]))
 # registers live at all of a set of probe points
-probes=[6000,10000,12750,15250,16250,17000]
+probes=[int(n*f) for f in (0.35,0.55,0.70,0.84,0.90,0.95)]          # (positions along the program: collision .. solver .. integrate)
 common=set.intersection(*[live_in[p] for p in probes])
 print('common live across probes',len(common),sorted(common))
 # find defs of those registers (all def sites)
