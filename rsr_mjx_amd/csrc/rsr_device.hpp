@@ -542,6 +542,11 @@ __device__ __forceinline__ int lrec_lane(int lane) {
   asm volatile("s_mov_b32 %0, 0" : "=s"(z));
   return lane + z;
 }
+// A value the optimiser may not look through (no instruction).  The factorisations compare a lane's position in its row with every
+// elimination step; the position is loop invariant, so the ~2 NCH lane masks of a factorisation were computed once per substep, kept
+// in SGPR pairs across the Newton loop, spilled there (the solver is short of SGPRs) and read back with two v_readlane per use --
+// 136 reads per Newton iteration of the cube kernel -- where the compare itself is one v_cmp into VCC.
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float asf(int x) { return __builtin_bit_cast(float, x); }
 __device__ __forceinline__ V3 v3_xyz(int4 r) { return V3{asf(r.x), asf(r.y), asf(r.z)}; }
 __device__ __forceinline__ V3 v3_yzw(int4 r) { return V3{asf(r.y), asf(r.z), asf(r.w)}; }
@@ -944,7 +949,7 @@ template <class C> __device__ __forceinline__ int rowchol_lane(int dof) {       
 template <class C, bool MASS_ONLY, bool HAS_DIAG = false>
 __device__ __forceinline__ float rowchol_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
   static_assert(C::ROWCHOL, "row-blocked factorisation needs both blocks within 16 lanes");
-  const int r = lane & 15, dofl = rowchol_dof<C>(lane);
+  const int r = opaque_v(lane & 15), dofl = rowchol_dof<C>(lane);
   const bool in_a = lane < 16 && dofl >= 0, in_b = lane >= 16 && dofl >= 0;
   // One exec region per block with compile-time column offsets (an address select per entry costs a VGPR each and the
   // kernel has none to spare); entries a lane does not own are zero
@@ -1032,7 +1037,7 @@ template <class C, bool HAS_DIAG = false>
 __device__ __forceinline__ float rowtree_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
   static_assert(C::ROWTREE, "per-tree factorisation");
   constexpr int N = C::NCT;
-  const int t = lane >> 4, p = lane & 15, dofl = rowtree_dof<C>(lane);
+  const int t = lane >> 4, p = opaque_v(lane & 15), dofl = rowtree_dof<C>(lane);
 #pragma unroll
   for (int c = 0; c < C::NCH; ++c) a[c] = 0.0f;
   // one exec region per tree with compile-time column offsets (see rowchol_factor)
@@ -1128,7 +1133,7 @@ template <class C, bool HAS_DIAG = false>
 __device__ __forceinline__ float arrow_factor(const float* src, float diag, float (&a)[C::NCH], float (&lt)[C::NCH], float* T, int lane) {
   static_assert(C::ARROW && C::NCH == 9, "block-arrow factorisation");
   constexpr int N = 9, NL = C::ALEGN;
-  const int row = lane >> 4, pos = lane & 15, dofl = arrow_dof<C>(lane);
+  const int row = lane >> 4, pos = opaque_v(lane & 15), dofl = arrow_dof<C>(lane);
   const bool trunk_copy = pos >= NL && row > 0;          // trunk lanes of rows 1..3: their trunk block starts at zero
 #pragma unroll
   for (int c = 0; c < N; ++c) a[c] = 0.0f;
