@@ -1376,6 +1376,7 @@ void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   }
   if (lane == 0) { s.acc_body = m.site_bodyid[m.env_ids[0]]; s.xfrc_body = 0; s.xfrc[0] = s.xfrc[1] = s.xfrc[2] = 0.0f; }
   WSYNC();
+  PROF(PS_LOAD)
   float Mrow[C::NV];
   FwdOut<C> f;
   for (int fr = 0; fr < m.n_frames; ++fr) {
@@ -1501,6 +1502,13 @@ void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     rec[L.priv_obs + lane] = priv[0];
     if (lane + 64 < GO2_PRIV) rec[L.priv_obs + lane + 64] = priv[1];
   }
+#ifdef RSR_PROFILE
+  PROF(PS_EPILOGUE)
+  if (a.debug && lane == 0) {
+    float* d = a.debug + (size_t)e * RSR_DEBUG_FLOATS + 7200;
+    for (int i = 0; i < PS_COUNT; ++i) d[i] = (float)prof_.acc[i];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- launchers of the Go2 kernels

@@ -30,6 +30,10 @@ if "--go2" in sys.argv:
     from rsr_mjx_amd.envs import go2
     env = go2.load("Go2JoystickFlatTerrain").batched(n, episode_length=1000, auto_reset=True)
     nu, astd = 12, 0.3
+elif "--handstand" in sys.argv:
+    from rsr_mjx_amd.envs import go2
+    env = go2.load("Go2Handstand").batched(n, episode_length=500, auto_reset=True)
+    nu, astd = 12, 0.3
 elif "--tshape" in sys.argv:
     from rsr_mjx_amd.envs.airbot import AirbotTShape
     envdef = AirbotTShape()
