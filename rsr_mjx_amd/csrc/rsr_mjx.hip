@@ -613,6 +613,17 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
 #pragma clang fp contract(off)
     const float* W = m.env_reward;
     float reward, met[C::NMET];
+    // the record words the wrapper code below reads back, fetched here in one batch: left at their uses they follow the metric
+    // stores (same base pointer, run-time offsets: the compiler must keep the order) and each waits out a memory round trip
+    float prev_done = 0.0f, em_old[2 + C::NMET];
+#pragma unroll
+    for (int i = 0; i < 2 + C::NMET; ++i) em_old[i] = 0.0f;
+    if (wrap_episode) {
+      prev_done = rec[L.episode_done];
+#pragma unroll
+      for (int i = 0; i < 2 + C::NMET; ++i) em_old[i] = rec[L.episode_metrics + i];
+    }
+    const float met_kept = rec[L.metrics + (ENV == ENV_TSHAPE ? 3 : 1)];      // the metric this env never writes
     if constexpr (ENV == ENV_TSHAPE) {
       const int site = m.env_ids[TID_SITE], tail = m.env_ids[TID_TAIL], ttail = m.env_ids[TID_TTAIL], tbody = m.env_ids[TID_T];
       float sp[3] = {s.spos[3 * site], s.spos[3 * site + 1], s.spos[3 * site + 2]};
@@ -650,7 +661,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
       reward = clampf(push + siet + health + site_z, -100.0f, 100.0f);
       done = s.xpos[3 * tbody + 2] < 0.6f ? 1.0f : 0.0f;
       tshape_obs<C>(m, s, tb, tv, xita, newT, obs_lds);
-      met[0] = push; met[1] = siet; met[2] = health; met[3] = rec[L.metrics + 3]; met[4] = site_z;
+      met[0] = push; met[1] = siet; met[2] = health; met[3] = met_kept; met[4] = site_z;
       rec[L.metrics + 0] = push; rec[L.metrics + 1] = siet; rec[L.metrics + 2] = health; rec[L.metrics + 4] = site_z;
       for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.T_pos + i] = s.xpos[3 * tbody + i]; }
       rec[L.new_T_pos] = newT[0]; rec[L.new_T_pos + 1] = newT[1];
@@ -682,7 +693,7 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
       reward = clampf(sf ? push + siet + health + task_complete + site_z : push + siet + health + site_z, -100.0f, 100.0f);
       done = sf ? (btd < W[4] ? 1.0f : 0.0f) : (cp[2] < 0.6f ? 1.0f : 0.0f);
       cube_obs<C>(m, s, tp, ncp, obs_lds);
-      met[0] = push; met[1] = rec[L.metrics + 1]; met[2] = siet;
+      met[0] = push; met[1] = met_kept; met[2] = siet;
       rec[L.metrics + 0] = push; rec[L.metrics + 2] = siet;
       for (int i = 0; i < 3; ++i) { rec[L.site_pos + i] = sp[i]; rec[L.cube_pos + i] = cp[i]; }
       rec[L.new_cube_pos] = ncp[0]; rec[L.new_cube_pos + 1] = ncp[1];
@@ -695,11 +706,11 @@ void step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a, Sched sc) 
       rec[L.truncation] = over ? 1.0f - done : 0.0f;
       // brax: metric = (metric + x) * (1 - prev_done).  Written as a select: the same value for finite metrics, and an env whose
       // simulation went non-finite once (a blow-up) starts its next episode's sums clean instead of carrying NaN * 0 = NaN forever.
-      float prev_done = rec[L.episode_done];
       float* em = rec + L.episode_metrics;
-      em[0] = prev_done != 0.0f ? 0.0f : em[0] + reward;
-      em[1] = prev_done != 0.0f ? 0.0f : em[1] + 1.0f;
-      for (int i = 0; i < C::NMET; ++i) em[2 + i] = prev_done != 0.0f ? 0.0f : em[2 + i] + met[i];
+      em[0] = prev_done != 0.0f ? 0.0f : em_old[0] + reward;
+      em[1] = prev_done != 0.0f ? 0.0f : em_old[1] + 1.0f;
+#pragma unroll
+      for (int i = 0; i < C::NMET; ++i) em[2 + i] = prev_done != 0.0f ? 0.0f : em_old[2 + i] + met[i];
       if (over) done = 1.0f;
       rec[L.episode_done] = done;
     }
