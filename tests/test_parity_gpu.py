@@ -294,18 +294,19 @@ def test_bench_line_contract():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["cube", "go2"])
+@pytest.mark.parametrize("kind", ["cube", "tshape", "go2", "handstand"])
 def test_odd_batch_sizes_and_argument_errors(setup, kind):
     """Batch sizes that are not multiples of anything (1, 3, 65): each env is the same env as in a larger batch; wrong
     action shapes and stepping before reset are refused on the host."""
     import torch
     from rsr_mjx_amd import prng
-    if kind == "cube":
-        envdef, nu = setup["envdef"], 5
+    if kind in ("cube", "tshape"):
+        from rsr_mjx_amd.envs.airbot import AirbotTShape
+        envdef, nu = (setup["envdef"] if kind == "cube" else AirbotTShape(device="cuda:0")), 5
         mk = lambda n: envdef.batched(n, episode_length=7, auto_reset=True)
     else:
         from rsr_mjx_amd.envs import go2
-        envdef, nu = go2.load("Go2JoystickFlatTerrain"), 12
+        envdef, nu = go2.load("Go2Handstand" if kind == "handstand" else "Go2JoystickFlatTerrain"), 12
         mk = lambda n: envdef.batched(n, episode_length=7, auto_reset=True)
     keys = prng.split(prng.PRNGKey(21), 65)
     acts = torch.clamp(torch.randn((12, 65, nu), generator=torch.Generator().manual_seed(1)) * 0.7, -1, 1).cuda()
