@@ -328,7 +328,7 @@ def main():
                 "num_envs_per_gpu": n, "parallelism": f"env-batch sharded by index over {world} GPU(s), no data-path collective",
                 "csrc_sha16": sha, "dr_keys": "replicated per GPU (RSR/train.py:212-217)" if args.replicated_dr else "global fan-out sliced per rank",
                 "kernel": {"cube": "rsr::step_kernel<CubeDims, ENV_CUBE>", "tshape": "rsr::step_kernel<TShapeDims, ENV_TSHAPE>",
-                           "go2": "rsr::go2_step_kernel<Go2Dims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>",
+                           "go2": "rsr::go2_step_kernel<Go2FlatDims>", "go2rough": "rsr::go2_step_kernel<Go2Dims>",
                            "handstand": "rsr::hs_step_kernel<HandDims>"}[args.workload]
                           + " (one wavefront per env" + ("" if args.workload.startswith("go2") or args.workload == "handstand" else "; persistent waves draw (env, substep) work units from a ticket queue") + ")",
                 "lds_bytes_per_env": int(env.dims.lds_bytes), "ncon_max": int(env.dims.ncon_max),

@@ -1420,19 +1420,25 @@ __device__ __forceinline__ V3 closest_on_triangle(V3 p, V3 a, V3 b, V3 c) {
 // sphere (geom2) vs height field (geom1): one contact at the closest point of the triangulated surface
 // (cells split along (col,row)-(col+1,row+1)); centre below the surface: perpendicular depth to the triangle above it.
 // Same construction as the oracle's hfield_sphere; the sphere spans at most two grid lines per axis (host check).
-__device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const float* hmat, V3 spos, float radius, float& dist, V3& pos, V3& nrm) {
+// In three parts: the pair's lane places the sphere (hfield_place); when its centre is above the surface the eight candidate
+// triangles of the 2 x 2 cells around it are searched ONE PER LANE (hfield_search, lane = 8 * pair + triangle) and the closest is
+// picked by an arg-min over the pair's eight lanes with the serial scan's tie rule (the first of equal minima) -- the scan of eight
+// closest_on_triangle calls by the pair's lane was ~12 % of the rough-terrain kernel's instructions; the pair's lane finishes
+// (hfield_finish).  Same arithmetic per triangle, same pick.
+struct HfJob { int state; V3 p, q, n; float dist, best; int c0, r0; };      // state: 0 no contact, 1 done (centre below), 2 search pending
+__device__ __forceinline__ void hfield_place(const DModel& m, V3 hpos, const float* hmat, V3 spos, float radius, HfJob& j) {
   const int nrow = m.hfield_nrow[0], ncol = m.hfield_ncol[0];
   const float sx = m.hfield_size[0], sy = m.hfield_size[1], sz = m.hfield_size[2];
   const float* __restrict__ data = m.hfield_data;
   V3 rel = spos - hpos;
   V3 p = v3(hmat[0] * rel.x + hmat[3] * rel.y + hmat[6] * rel.z, hmat[1] * rel.x + hmat[4] * rel.y + hmat[7] * rel.z,
             hmat[2] * rel.x + hmat[5] * rel.y + hmat[8] * rel.z);
-  if (p.x < -sx || p.x > sx || p.y < -sy || p.y > sy) return false;
+  j.state = 0; j.p = p;
+  if (p.x < -sx || p.x > sx || p.y < -sy || p.y > sy) return;
   const float dx = 2.0f * sx / (float)(ncol - 1), dy = 2.0f * sy / (float)(nrow - 1);      // (wave-uniform: scalar code)
   const float rdx = frcp(dx), rdy = frcp(dy);
   int ci = (int)floorf((p.x + sx) * rdx), ri = (int)floorf((p.y + sy) * rdy);
   ci = ci < 0 ? 0 : (ci > ncol - 2 ? ncol - 2 : ci); ri = ri < 0 ? 0 : (ri > nrow - 2 ? nrow - 2 : ri);
-  V3 n, q;
   float x0 = -sx + dx * (float)ci, y0 = -sy + dy * (float)ri;
   float u = (p.x - x0) * rdx, v = (p.y - y0) * rdy;
   float z00 = data[ri * ncol + ci] * sz, z10 = data[ri * ncol + ci + 1] * sz, z01 = data[(ri + 1) * ncol + ci] * sz, z11 = data[(ri + 1) * ncol + ci + 1] * sz;
@@ -1441,29 +1447,65 @@ __device__ __forceinline__ bool hfield_sphere(const DModel& m, V3 hpos, const fl
   else { gx = (z11 - z01) * rdx; gy = (z01 - z00) * rdy; zs = z00 + (z11 - z01) * u + (z01 - z00) * v; }
   if (p.z < zs) {
     float inv = frsq(gx * gx + gy * gy + 1.0f);
-    n = v3(-gx * inv, -gy * inv, inv);
+    j.n = v3(-gx * inv, -gy * inv, inv);
     float depth = (zs - p.z) * inv;
-    dist = -depth - radius;
-    q = p + n * depth;
+    j.dist = -depth - radius;
+    j.q = p + j.n * depth;
+    j.state = 1;
   } else {
     int c0 = (int)floorf((p.x - radius + sx) * rdx), r0 = (int)floorf((p.y - radius + sy) * rdy);
-    c0 = c0 < 0 ? 0 : (c0 > ncol - 3 ? ncol - 3 : c0); r0 = r0 < 0 ? 0 : (r0 > nrow - 3 ? nrow - 3 : r0);
-    float best = 1e30f;
-    q = p;
-    for (int j = 0; j < 2; ++j)
-      for (int i = 0; i < 2; ++i) {
-        int cc = c0 + i, rr = r0 + j;
-        float xa = -sx + dx * (float)cc, ya = -sy + dy * (float)rr, xb = xa + dx, yb = ya + dy;
-        V3 v00 = v3(xa, ya, data[rr * ncol + cc] * sz), v10 = v3(xb, ya, data[rr * ncol + cc + 1] * sz);
-        V3 v01 = v3(xa, yb, data[(rr + 1) * ncol + cc] * sz), v11 = v3(xb, yb, data[(rr + 1) * ncol + cc + 1] * sz);
-        V3 qa = closest_on_triangle(p, v00, v10, v11);
-        V3 da = p - qa; float d2a = dot(da, da);
-        if (d2a < best) { best = d2a; q = qa; }
-        V3 qb = closest_on_triangle(p, v00, v11, v01);
-        V3 db = p - qb; float d2b = dot(db, db);
-        if (d2b < best) { best = d2b; q = qb; }
-      }
-    float dn = fsqrt(best);
+    j.c0 = c0 < 0 ? 0 : (c0 > ncol - 3 ? ncol - 3 : c0); j.r0 = r0 < 0 ? 0 : (r0 > nrow - 3 ? nrow - 3 : r0);
+    j.state = 2;
+  }
+}
+// All lanes (uniform control flow).  Lane 8 f + k searches triangle k = (row j, column i, half t) = bits (2, 1, 0) of pair lane f's
+// 2 x 2 cells -- the serial scan's order -- and lane f receives the closest point and its squared distance.
+template <int NPAIR>
+__device__ __forceinline__ void hfield_search(const DModel& m, int lane, HfJob& j) {
+  static_assert(8 * NPAIR <= 64, "eight lanes per height-field pair");
+  const int f = lane >> 3, k = lane & 7, src = f < NPAIR ? f : 0;
+  const int st = __shfl(j.state, src);
+  const V3 p = v3(__shfl(j.p.x, src), __shfl(j.p.y, src), __shfl(j.p.z, src));
+  const int c0 = __shfl(j.c0, src), r0 = __shfl(j.r0, src);
+  const bool work = f < NPAIR && st == 2;
+  float d2 = 3.0e38f; V3 q = p;
+  if (work) {
+    const int ncol = m.hfield_ncol[0], nrow = m.hfield_nrow[0];
+    const float sx = m.hfield_size[0], sy = m.hfield_size[1], sz = m.hfield_size[2];
+    const float* __restrict__ data = m.hfield_data;
+    const float dx = 2.0f * sx / (float)(ncol - 1), dy = 2.0f * sy / (float)(nrow - 1);
+    const int cc = c0 + ((k >> 1) & 1), rr = r0 + (k >> 2);
+    float xa = -sx + dx * (float)cc, ya = -sy + dy * (float)rr, xb = xa + dx, yb = ya + dy;
+    V3 v00 = v3(xa, ya, data[rr * ncol + cc] * sz), v10 = v3(xb, ya, data[rr * ncol + cc + 1] * sz);
+    V3 v01 = v3(xa, yb, data[(rr + 1) * ncol + cc] * sz), v11 = v3(xb, yb, data[(rr + 1) * ncol + cc + 1] * sz);
+    q = (k & 1) ? closest_on_triangle(p, v00, v11, v01) : closest_on_triangle(p, v00, v10, v11);
+    V3 d = p - q; d2 = dot(d, d);
+  }
+  // arg-min over the eight lanes of the pair, first of equal minima
+  float bv = d2; int bi = k;
+#pragma unroll
+  for (int stp = 0; stp < 3; ++stp) {
+    float ov; int oi;
+    if (stp == 0) { ov = dpp_mov<0xB1>(bv); oi = __builtin_bit_cast(int, dpp_mov<0xB1>(__builtin_bit_cast(float, bi))); }
+    else if (stp == 1) { ov = dpp_mov<0x4E>(bv); oi = __builtin_bit_cast(int, dpp_mov<0x4E>(__builtin_bit_cast(float, bi))); }
+    else { ov = dpp_mov<0x141>(bv); oi = __builtin_bit_cast(int, dpp_mov<0x141>(__builtin_bit_cast(float, bi))); }
+    const bool take = ov < bv || (ov == bv && oi < bi);
+    bv = take ? ov : bv; bi = take ? oi : bi;
+  }
+  // back to the pair's lane: lane f reads its group's winner
+  const int grp = lane < NPAIR ? 8 * lane : 0;
+  const int kw = __shfl(bi, grp);
+  const float best = __shfl(bv, grp);
+  const V3 qw = v3(__shfl(q.x, grp + kw), __shfl(q.y, grp + kw), __shfl(q.z, grp + kw));
+  if (lane < NPAIR && j.state == 2) { j.q = qw; j.best = best; }
+}
+__device__ __forceinline__ bool hfield_finish(V3 hpos, const float* hmat, float radius, const HfJob& j, float& dist, V3& pos, V3& nrm) {
+  if (j.state == 0) return false;
+  V3 n = j.n, q = j.q;
+  dist = j.dist;
+  if (j.state == 2) {
+    const V3 p = j.p;
+    float dn = fsqrt(j.best);
     n = v3(0, 0, 1);
     if (!(dn < 1e-12f)) { const float rdn = frcp(dn); n = v3((p.x - q.x) * rdn, (p.y - q.y) * rdn, (p.z - q.z) * rdn); }
     dist = dn - radius;
@@ -1481,6 +1523,8 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
   float incl = 0.0f;
   const int lr = lrec_lane(lane);
   const int4 rp0 = lrec<C>(h, LQ_P_0, lr), rp1 = lrec<C>(h, LQ_P_1, lr), rp2 = lrec<C>(h, LQ_P_2, lr);
+  HfJob hf; hf.state = 0;          // (Dims::HFIELD; the other fields are written by hfield_place and read only where state != 0)
+  int hf_g1 = 0; float hf_radius = 0.0f; V3 hf_hpos = v3(0, 0, 0);
   if (lane < C::NP) {
     const int g1 = rp0.x, g2 = rp0.y, kind = rp0.z;
     incl = asf(rp0.w);
@@ -1550,10 +1594,14 @@ __device__ __forceinline__ void collision(const DModel& m, const Hot& h, Smem<C>
       }
     }
     if constexpr (C::HFIELD) {
-      if (kind == PAIR_HFIELD_SPHERE) {
-        float dist; V3 pos, n;
-        if (hfield_sphere(m, p1, &s.x.a.gmat[9 * g1], p2, size2.x, dist, pos, n)) { pts.n = n; pts.dist[0] = dist; pts.pos[0] = pos; pts.cnt = 1; }
-      }
+      if (kind == PAIR_HFIELD_SPHERE) { hfield_place(m, p1, &s.x.a.gmat[9 * g1], p2, size2.x, hf); hf_g1 = g1; hf_radius = size2.x; hf_hpos = p1; }
+    }
+  }
+  if constexpr (C::HFIELD) {
+    if (__ballot(hf.state == 2) != 0ull) hfield_search<C::NP>(m, lane, hf);       // (wave-uniform: every lane takes part)
+    if (hf.state != 0) {
+      float dist; V3 pos, n;
+      if (hfield_finish(hf_hpos, &s.x.a.gmat[9 * hf_g1], hf_radius, hf, dist, pos, n)) { pts.n = n; pts.dist[0] = dist; pts.pos[0] = pos; pts.cnt = 1; }
     }
   }
   PROF(PS_X0)

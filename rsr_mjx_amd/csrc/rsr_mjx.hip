@@ -25,6 +25,10 @@ using CubeDims = Dims<22, 20, 5, 14, 10, 23, 1, 45, 1, 8, 8, /*NCON*/ RSR_CUBE_N
 // Unitree Go2 feet-only: nq 19, nv 18, nu 12, 13 joints, 39 geoms, 6 sites, 4 sphere-plane pairs of condim 3
 using Go2Dims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
                      /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ true, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true, /*ARROW*/ true>;
+// the same without the height-field narrow phase, for models whose floor is a plane (the flat-terrain joystick): the kernel is picked
+// by the model (rsr_model_create: any PAIR_HFIELD_SPHERE pair)
+using Go2FlatDims = Dims<19, 18, 12, 14, 13, 39, 6, 4, /*NEQ*/ 0, /*NF*/ 12, /*NL*/ 12, /*NCON*/ 4, /*OBS*/ 48, /*NMET*/ 22, 0, 0, /*CONDIM*/ 3,
+                     /*NINFO*/ 144, /*ISO*/ 0, 0, /*DREX*/ true, /*HFIELD*/ false, /*TALIAS*/ false, /*NGA: floor or height field + four feet*/ 5, /*TTAIL*/ true, /*ARROW*/ true>;
 // Unitree Go2 with every collision geom against the floor (go2_mjx.xml + scene_mjx_flat_terrain.xml, the Handstand / Footstand tasks): 44 geoms,
 // 30 plane pairs of condim 3 (4 spheres, 20 capsules, 6 cylinders: up to 62 contact points, 12 kept active per env -- a state with
 // more is a fall, which ends the episode in the same step)
@@ -1526,8 +1530,8 @@ void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
 // The Go2 kernels are built as a translation unit of their own (this file with -DRSR_TU_GO2 -fno-slp-vectorize, see
 // rsr_mjx_amd/build.py): the SLP vectoriser's packed-fp32 pairing costs them ~3% while it gains the Airbot kernels ~1%.
 // Kernel templates are instantiated where they are launched, so each unit compiles only its own kernels.
-void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
-void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield);
+void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield);
 void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 // The T-shape kernels likewise (-DRSR_TU_TSHAPE -fno-slp-vectorize: +3 % for them, measured; the cube kernels keep the vectoriser).
@@ -1553,11 +1557,14 @@ void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs
 void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
   hipLaunchKernelGGL((hs_step_kernel<HandDims>), dim3(n), dim3(64), sizeof(Smem<HandDims>), st, dm, L, a);
 }
-void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
-  hipLaunchKernelGGL((go2_reset_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield) {
+  if (hfield) hipLaunchKernelGGL((go2_reset_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+  else hipLaunchKernelGGL((go2_reset_kernel<Go2FlatDims>), dim3(n), dim3(64), sizeof(Smem<Go2FlatDims>), st, dm, L, a);
 }
-void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a) {
-  hipLaunchKernelGGL((go2_step_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield) {
+  static_assert(sizeof(Smem<Go2FlatDims>) == sizeof(Smem<Go2Dims>), "one LDS image for both Go2 joystick kernels (rsr_model_dims reports it)");
+  if (hfield) hipLaunchKernelGGL((go2_step_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
+  else hipLaunchKernelGGL((go2_step_kernel<Go2FlatDims>), dim3(n), dim3(64), sizeof(Smem<Go2FlatDims>), st, dm, L, a);
 }
 #endif
 
@@ -1603,6 +1610,7 @@ struct rsr_model {
   std::vector<char> blob;
   rsr_dims dims;
   Layout layout;
+  bool has_hfield = false;      // any PAIR_HFIELD_SPHERE pair: the Go2 kernels with the height-field narrow phase
   const void* find(const char* name, int* count = nullptr) const {
     const int32_t* h = reinterpret_cast<const int32_t*>(blob.data());
     const blob_entry* e = reinterpret_cast<const blob_entry*>(blob.data() + 16);
@@ -1794,6 +1802,7 @@ extern "C" int rsr_model_create(const void* blob, size_t nbytes, rsr_model** out
     int npk = 0, nh = 0, nsz = 0; const int* pk = static_cast<const int*>(m->find("pair_kind", &npk));
     bool any_hf = false;
     for (int i = 0; pk && i < npk; ++i) any_hf |= (pk[i] == rsr::PAIR_HFIELD_SPHERE);
+    m->has_hfield = any_hf;
     if (any_hf) {
       const int* hr = static_cast<const int*>(m->find("hfield_nrow", &nh));
       const int* hc = static_cast<const int*>(m->find("hfield_ncol"));
@@ -2022,7 +2031,7 @@ extern "C" int rsr_reset(rsr_batch* b, const uint32_t* keys, void* hip_stream) {
   a.keys = keys;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
-    rsr::launch_go2_reset(b->n, st, b->dmodel, b->model->layout, a);
+    rsr::launch_go2_reset(b->n, st, b->dmodel, b->model->layout, a, b->model->has_hfield);
   else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
     rsr::launch_hs_reset(b->n, st, b->dmodel, b->model->layout, a);
   else if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
@@ -2041,7 +2050,7 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   a.action = action;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (b->model->dims.env_kind == rsr::ENV_GO2)
-    rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a);
+    rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a, b->model->has_hfield);
   else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
     rsr::launch_hs_step(b->n, st, b->dmodel, b->model->layout, a);
   else {
