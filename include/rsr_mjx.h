@@ -126,6 +126,17 @@ int rsr_batch_set_schedule(rsr_batch* b, int units);
  * one finished two rounds ago instead of waiting for it); 0: every env is split (the behaviour before round 3). */
 int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs);
 
+/* Third scheduling knob, for the step kernels that run as a plain launch of one wavefront per env (Go2 joystick, Go2 handstand):
+ * the hardware priority (s_setprio) a wave asks for at the top of each physics substep.  Timing only: results are bit-identical
+ * for every value (tests/test_go2.py::test_wave_priority_policies_are_bit_identical).
+ *   0  off: every wave at priority 0; the SIMD then serves its oldest wave first and its waves finish one after another;
+ *   1  rotate: (wave slot + substep) mod 4 -- waves that start together take turns and finish together;
+ *   2  catch up: least progress first, and the waves of the launch's final resident set keep a floor that grows with their
+ *      start time, so that the set finishes together instead of draining one wave per SIMD at a time;
+ *  -1  (default) joystick kernels: 1 for a batch of at most one resident round of envs (4096 on MI355X), 2 above; handstand: 1.
+ * No counterpart in the reference (XLA schedules its own kernels).  The Airbot kernels (work queue) ignore it. */
+int rsr_batch_set_priority(rsr_batch* b, int policy);
+
 /* Health of the work queue.  A phase of an env waits for the previous phase's hand-off with a bounded spin; a wait that
  * times out is counted on the device (sticky for the batch's lifetime), the env's later phases inherit the mark, and the
  * env's stats[3] reads -1 after that step.  rsr_batch_check synchronises `hip_stream`, copies the count to

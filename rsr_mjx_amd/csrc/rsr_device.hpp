@@ -150,7 +150,41 @@ struct StepArgs {
   const float *dr_body_ipos, *dr_qpos0, *dr_dof_armature, *dr_gainprm, *dr_biasprm;
   float* debug;                 // [N][RSR_DEBUG_FLOATS] or null
   int n;
+  int prio_mode, prio_slots;    // wave priority schedule of the plain-launch (Go2-family) step kernels: policy, resident waves of the device
 };
+
+// ---- wave priority schedule of the plain-launch step kernels (rsr_batch_set_priority) ----
+// The SIMD arbitrates between its resident waves by priority, then by age: left alone (all at priority 0) the oldest wave of a SIMD
+// runs nearly unimpeded and the youngest takes the leftover issue slots, so waves that start together finish one after another
+// (Go2, four per SIMD: 104 / 125 / 147 / 172 us) and the launch ends with SIMDs holding three, two, one wave for a quarter of its
+// makespan.  s_setprio at the top of every substep evens the finish times out; results do not depend on it (timing only).
+//   RSR_PRIO_ROTATE   (slot + substep) mod 4: the four waves of a SIMD take turns -- for waves that start together (a batch of at
+//                     most one resident round);
+//   RSR_PRIO_CATCH_UP outside the launch's final resident set: least progress first (3, 2, 1, 0, 0 ... by substep); in the final
+//                     set, whose waves start as the slots of the round before fall free: max(that, the quarter of the set the wave
+//                     belongs to by index = by start time), so the later a wave starts the longer it keeps the right of way.
+enum { RSR_PRIO_OFF = 0, RSR_PRIO_ROTATE = 1, RSR_PRIO_CATCH_UP = 2 };
+__device__ __forceinline__ void set_prio(int p) {      // p wave-uniform; s_setprio takes an immediate
+  switch (__builtin_amdgcn_readfirstlane(p) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+// quarter of the final resident set env e belongs to (0 = its first starters), or -1 outside the set
+__device__ __forceinline__ int prio_quarter(const StepArgs& a, int e) {
+  const int first = a.n - a.prio_slots;
+  return e >= first ? ((e - first) * 4) / a.prio_slots : -1;
+}
+__device__ __forceinline__ void prio_substep(int mode, int quarter, int fr) {
+  if (mode == RSR_PRIO_OFF) return;
+  const int progress = fr >= 3 ? 0 : 3 - fr;
+  int p;
+  if (mode == RSR_PRIO_ROTATE) p = ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3) + fr) & 3;      // HW_ID: wave slot of the SIMD
+  else p = quarter > progress ? quarter : progress;
+  set_prio(p);
+}
 
 // ---- compile-time dimensions of one model family ----
 template <int NQ_, int NV_, int NU_, int NB_, int NJ_, int NG_, int NS_, int NP_, int NEQ_, int NF_, int NL_,

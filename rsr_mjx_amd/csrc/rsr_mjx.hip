@@ -938,6 +938,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   PROF(PS_LOAD)
   float Mrow[C::NV];
   FwdOut<C> f;
+  const int prio_q = prio_quarter(a, e);
   for (int fr = 0; fr < m.n_frames; ++fr) {
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
@@ -945,6 +946,7 @@ void go2_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
 #endif
     const int lane_s = lrec_lane(lane);        // see step_kernel
+    prio_substep(a.prio_mode, prio_q, fr);
     forward<C>(m, hot, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
     integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
     time += hot.timestep;
@@ -1394,6 +1396,7 @@ void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
   PROF(PS_LOAD)
   float Mrow[C::NV];
   FwdOut<C> f;
+  const int prio_q = prio_quarter(a, e);
   for (int fr = 0; fr < m.n_frames; ++fr) {
 #if defined(RSR_PROFILE) || defined(RSR_TIMELINE)
     float* dbg = nullptr;
@@ -1401,6 +1404,7 @@ void hs_step_kernel(const DModel* __restrict__ mp, Layout L, StepArgs a) {
     float* dbg = (a.debug && fr == m.n_frames - 1) ? a.debug + (size_t)e * RSR_DEBUG_FLOATS : nullptr;
 #endif
     const int lane_s = lrec_lane(lane);
+    prio_substep(a.prio_mode, prio_q, fr);
     forward<C>(m, hot, s, lane_s, Mrow, warm, f, dbg PROF_PASS);
     integrate<C>(m, hot, s, lane_s, Mrow, f PROF_PASS);
     time += hot.timestep;
@@ -1534,6 +1538,7 @@ void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArg
 void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield);
 void launch_hs_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
+int go2_step_occupancy(int kind, bool hfield);
 // The T-shape kernels likewise (-DRSR_TU_TSHAPE -fno-slp-vectorize: +3 % for them, measured; the cube kernels keep the vectoriser).
 void launch_tshape_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a);
 void launch_tshape_step(int grid, hipStream_t st, const DModel* dm, Layout L, StepArgs a, Sched sc);
@@ -1560,6 +1565,14 @@ void launch_hs_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs 
 void launch_go2_reset(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield) {
   if (hfield) hipLaunchKernelGGL((go2_reset_kernel<Go2Dims>), dim3(n), dim3(64), sizeof(Smem<Go2Dims>), st, dm, L, a);
   else hipLaunchKernelGGL((go2_reset_kernel<Go2FlatDims>), dim3(n), dim3(64), sizeof(Smem<Go2FlatDims>), st, dm, L, a);
+}
+int go2_step_occupancy(int kind, bool hfield) {       // resident workgroups per CU of the step kernel (kind 1: handstand)
+  int per_cu = 0;
+  hipError_t e;
+  if (kind == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hs_step_kernel<HandDims>, 64, sizeof(Smem<HandDims>));
+  else if (hfield) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, go2_step_kernel<Go2Dims>, 64, sizeof(Smem<Go2Dims>));
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, go2_step_kernel<Go2FlatDims>, 64, sizeof(Smem<Go2FlatDims>));
+  return e == hipSuccess ? per_cu : 0;
 }
 void launch_go2_step(int n, hipStream_t st, const DModel* dm, Layout L, StepArgs a, bool hfield) {
   static_assert(sizeof(Smem<Go2FlatDims>) == sizeof(Smem<Go2Dims>), "one LDS image for both Go2 joystick kernels (rsr_model_dims reports it)");
@@ -1642,6 +1655,7 @@ struct rsr_batch {
   int units, step_grid;
   int spin_cap, withhold_env;   // rsr_batch_set_fault_injection (test hook)
   int whole_envs;               // rsr_batch_set_whole_envs: envs stepped as one unit each (-1: all but two resident rounds' worth)
+  int prio_policy, prio_slots;  // rsr_batch_set_priority (-1: chosen from the batch size per launch); resident waves of the step kernel
 };
 
 static Layout make_layout(const rsr_dims& d) {
@@ -1915,6 +1929,14 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   int rc = fill_dmodel(m, b->dblob, b->dm);
   if (rc) { release(); return rc; }
   b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1; b->whole_envs = -1;
+  b->prio_policy = -1; b->prio_slots = 1;
+  if (m->dims.env_kind == rsr::ENV_GO2 || m->dims.env_kind == rsr::ENV_GO2_HANDSTAND) {
+    int per_cu = rsr::go2_step_occupancy(m->dims.env_kind == rsr::ENV_GO2_HANDSTAND ? 1 : 0, m->has_hfield);
+    hipDeviceProp_t prop;
+    if (per_cu <= 0 || hipGetDeviceProperties(&prop, hip_device) != hipSuccess) { per_cu = 16; prop.multiProcessorCount = 256; }
+    b->prio_slots = per_cu * prop.multiProcessorCount;
+    if (const char* pv = std::getenv("RSR_PRIO_MODE")) b->prio_policy = std::atoi(pv);    // diagnostic (tools/ab_bench.py)
+  }
   if (m->dims.env_kind != rsr::ENV_GO2 && m->dims.env_kind != rsr::ENV_GO2_HANDSTAND) {
     const size_t sb = (4 + (size_t)num_envs) * sizeof(int);
     if (hipMalloc(&b->sched, sb) != hipSuccess) { b->sched = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(sched)"); }
@@ -1933,6 +1955,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
     if (b->units > m->dims.n_frames) b->units = m->dims.n_frames;
     if (b->units > RSR_MAX_UNITS) b->units = RSR_MAX_UNITS;
     if (const char* wv = std::getenv("RSR_WHOLE_ENVS")) b->whole_envs = std::atoi(wv);      // diagnostic (tools/ab_bench.py)
+    b->prio_policy = 0;      // the work queue balances itself: rotate / final-set priorities measured at +-0.2 % on the cube and the T-shape
   }
   if (hipMalloc(&b->dmodel, sizeof(DModel)) != hipSuccess) { b->dmodel = nullptr; release(); return fail(RSR_ERR_NOMEM, "rsr_batch_create: hipMalloc(dmodel)"); }
   { hipError_t ce = hipMemcpy(b->dmodel, &b->dm, sizeof(DModel), hipMemcpyHostToDevice);
@@ -1989,6 +2012,12 @@ extern "C" int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs) {
   return RSR_OK;
 }
 
+extern "C" int rsr_batch_set_priority(rsr_batch* b, int policy) {
+  if (!b || policy > rsr::RSR_PRIO_CATCH_UP) return fail(RSR_ERR_ARG, "rsr_batch_set_priority: bad argument");
+  b->prio_policy = policy < 0 ? -1 : policy;
+  return RSR_OK;
+}
+
 extern "C" int rsr_batch_set_fault_injection(rsr_batch* b, int spin_cap, int withhold_env) {
   if (!b) return fail(RSR_ERR_ARG, "rsr_batch_set_fault_injection: null batch");
   b->spin_cap = spin_cap > 0 ? spin_cap : RSR_SPIN_CAP_DEFAULT;
@@ -2021,6 +2050,11 @@ static rsr::StepArgs make_args(rsr_batch* b) {
   a.dr_geom_friction = b->dr_fric; a.dr_body_mass = b->dr_mass; a.dr_dof_damping = b->dr_damp; a.dr_dof_frictionloss = b->dr_floss;
   a.dr_body_ipos = b->dr_ex[0]; a.dr_qpos0 = b->dr_ex[1]; a.dr_dof_armature = b->dr_ex[2]; a.dr_gainprm = b->dr_ex[3]; a.dr_biasprm = b->dr_ex[4];
   a.debug = b->debug;
+  // default: waves that start together take turns; a joystick batch of more than one resident round lets its late starters catch up
+  // (measured per kernel family and batch size: DESIGN.md 4)
+  const bool rotate = b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND || b->n <= b->prio_slots;
+  a.prio_mode = b->prio_policy >= 0 ? b->prio_policy : (rotate ? rsr::RSR_PRIO_ROTATE : rsr::RSR_PRIO_CATCH_UP);
+  a.prio_slots = b->prio_slots;
   return a;
 }
 

@@ -248,6 +248,11 @@ class BatchedEnv:
         _lib.check(_lib.lib().rsr_rollout_metrics(self._batch, C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def set_priority(self, policy: int = -1) -> None:
+        """Wave priority schedule of the plain-launch step kernels (rsr_batch_set_priority: 0 off, 1 rotate, 2 catch up, -1 by batch
+        size); timing only, results are bit-identical."""
+        _lib.check(_lib.lib().rsr_batch_set_priority(self._batch, int(policy)))
+
     def handoff_timeouts(self) -> int:
         """Synchronises the launch stream and returns the number of work-unit hand-off waits that timed out since the batch was
         created (rsr_batch_check; 0 on a healthy batch).  The envs concerned read stats[:, 3] == -1 after that step."""

@@ -501,3 +501,31 @@ def test_go2_truncation_and_autoreset_on_device(oracle_mod):
         saw_fall += int((done & (st["info_truncation"] == 0)).sum())
         saw_trunc += int((st["info_truncation"] != 0).sum())
     assert saw_fall >= n // 3 and saw_trunc >= n, (saw_fall, saw_trunc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,nu", [("Go2JoystickFlatTerrain", 12), ("Go2JoystickRoughTerrain", 12), ("Go2Handstand", 12)])
+def test_wave_priority_policies_are_bit_identical(task, nu):
+    """include/rsr_mjx.h, rsr_batch_set_priority: the wave priority schedule of the plain-launch step kernels moves issue slots
+    between the waves of a SIMD and nothing else.  One batch runs with the schedule off; the other changes the policy between the
+    steps of ONE rollout (off / rotate / catch up / by batch size), across truncation and auto-reset (episode_length 7), at a batch
+    of more than one resident round (the final-set quarters of policy 2 are in play) -- records compared as int32 after every step."""
+    import torch
+    from rsr_mjx_amd.envs import go2
+    n, steps = 4608, 16
+    envdef = go2.load(task)
+    a = envdef.batched(n, episode_length=7, auto_reset=True)
+    b = envdef.batched(n, episode_length=7, auto_reset=True)
+    keys = prng.split(prng.PRNGKey(77), n)
+    a.reset(keys); b.reset(keys)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    acts = torch.clamp(torch.randn((steps, n, nu), generator=gen, device="cuda") * 0.5, -1, 1)
+    a.set_priority(0)
+    order = [2, 1, -1, 0, 2, 2, 1, -1]
+    for t in range(steps):
+        b.set_priority(order[t % len(order)])
+        a.step(None, acts[t]); b.step(None, acts[t])
+        assert torch.equal(a.record.view(torch.int32), b.record.view(torch.int32)), (task, "step", t, "policy", order[t % len(order)])
+    assert float(a.view("info_steps").max()) <= 7.0
+    with pytest.raises(Exception):
+        b.set_priority(3)
