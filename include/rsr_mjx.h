@@ -123,7 +123,8 @@ int rsr_batch_set_schedule(rsr_batch* b, int units);
  * ONE work unit each whatever `units` says (no hand-off through memory, one ticket), only the rest is cut into `units` phases.
  * Long units first, short units last: the launch still drains in short units while most envs skip the per-unit overhead.
  * -1 (the default): all but twice as many envs as there are resident waves (a phase of a split env then finds the previous
- * one finished two rounds ago instead of waiting for it); 0: every env is split (the behaviour before round 3). */
+ * one finished two rounds ago instead of waiting for it), and every env of a batch that fits the resident waves (2048 on MI355X);
+ * 0: every env is split (the behaviour before round 3). */
 int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs);
 
 /* Third scheduling knob, for the step kernels that run as a plain launch of one wavefront per env (Go2 joystick, Go2 handstand):

@@ -181,7 +181,8 @@ __device__ __forceinline__ void prio_substep(int mode, int quarter, int fr) {
   if (mode == RSR_PRIO_OFF) return;
   const int progress = fr >= 3 ? 0 : 3 - fr;
   int p;
-  if (mode == RSR_PRIO_ROTATE) p = ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3) + fr) & 3;      // HW_ID: wave slot of the SIMD
+  const int rot = ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3) + fr) & 3;      // HW_ID: wave slot of the SIMD
+  if (mode == RSR_PRIO_ROTATE) p = rot;
   else p = quarter > progress ? quarter : progress;
   set_prio(p);
 }

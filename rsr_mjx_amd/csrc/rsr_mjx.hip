@@ -2094,8 +2094,9 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
       HIPCHK(hipMemsetAsync(b->sched + 4, 0, (size_t)b->n * sizeof(int), st));
     }
     // envs stepped as one unit: by default all but two resident rounds' worth (the launch then still drains in short units, with
-    // a slack of two resident rounds between the phases of a split env)
-    int n_whole = b->units <= 1 ? b->n : (b->whole_envs >= 0 ? b->whole_envs : (b->n > 2 * b->step_grid ? b->n - 2 * b->step_grid : 0));
+    // a slack of two resident rounds between the phases of a split env); a batch that fits the resident waves is not split at all
+    // (every env has a wave to itself from the start: phases would only add hand-offs; 1024 envs 3.64 -> 4.48 M env-steps/s)
+    int n_whole = b->units <= 1 ? b->n : (b->whole_envs >= 0 ? b->whole_envs : (b->n <= b->step_grid ? b->n : (b->n > 2 * b->step_grid ? b->n - 2 * b->step_grid : 0)));
     if (n_whole > b->n) n_whole = b->n;
     rsr::Sched sc{b->sched, b->sched + 2, reinterpret_cast<unsigned*>(b->sched + 4), b->launch_id, b->units, n_whole, b->spin_cap, b->withhold_env};
     const long long work = (long long)n_whole + (long long)b->units * (b->n - n_whole);

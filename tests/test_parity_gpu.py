@@ -570,6 +570,7 @@ def test_handoff_timeout_is_sticky_and_visible():
     clean.reset(keys); hurt.reset(keys)
     act = torch.clamp(torch.randn((n, 5), generator=torch.Generator(device="cuda").manual_seed(4), device="cuda"), -1, 1)
     clean.set_schedule(4); hurt.set_schedule(4)
+    clean.set_whole_envs(0); hurt.set_whole_envs(0)       # (a batch that fits the resident waves is not split by default: no hand-offs)
     hurt.set_fault_injection(spin_cap=8192, withhold_env=victim)
     clean.step(None, act); hurt.step(None, act)
     st = hurt.view("stats").cpu().numpy()
