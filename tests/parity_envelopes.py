@@ -4,7 +4,8 @@ The envelopes derive from what was measured on an MI355X over 2048 envs x 3 roll
 (tools/gpu_parity_stats.py -> tools/make_parity_envelopes.py; the JSON keeps the measured values and the hash of the kernel
 sources they were measured on).  err = |hip - oracle| / max(1, |oracle|_inf of that env's field), per env.  For every
 (workload, phase, field), with max = max(1e-5, 5 x the measured maximum):
-  samples of >= 1000 envs:  99.9 % of the envs within max, none beyond 30 x max, quantile(err, 0.99) <= p99;
+  samples of >= 1000 envs:  99.9 % of the envs within max, none beyond min(30 x max, max(3 x max, 10 x the fp32-oracle-to-fp64-oracle
+                            distance measured on the field)) (hard_cap), quantile(err, 0.99) <= p99;
   smaller samples:          at most ONE env above max and none beyond 5 x max (the 4-env goldens, the 64-env wrapper tests:
                             a small sample has no quantiles to speak of, so it is held to the bound itself);
   and at most 1 % of the envs above 1e-5 where the measurement found none (obs, reward, xpos ... on the Airbot envs).
@@ -43,6 +44,16 @@ def bound(kind, phase, field, what="max"):
     return ENV[kind][phase][field][what]
 
 
+def hard_cap(e):
+    """What no env of a large sample may pass: 30 x the bound (150 x the measured maximum) at most, and where the physics says less,
+    less -- ten times the distance between the fp32 oracle and its own fp64 build on that field (a HIP result farther from the fp32
+    oracle than fp32 arithmetic is from fp64 arithmetic is not rounding), but never under 3 x the bound."""
+    spread = e["measured"].get("f32_vs_f64_max")
+    if spread is None:
+        return 30.0 * e["max"]
+    return min(30.0 * e["max"], max(3.0 * e["max"], 10.0 * spread))
+
+
 def check(kind, phase, field, got, want, tag="", quantiles=True, outliers=0):
     """Asserts the envelope of (kind, phase, field) on the per-env scaled error of `got` against `want`; returns the errors.
     Fields without an envelope are values the step only passes through (targets, constants): exact to 1e-6.  The 99 % quantile
@@ -61,8 +72,9 @@ def check(kind, phase, field, got, want, tag="", quantiles=True, outliers=0):
     # measured maximum of a 6000-sample run): in a large sample one env in a thousand may pass the bound, none may pass 30 x it;
     # a small sample is held to the bound itself -- one env may pass it, by less than 5 x
     if len(err) >= 1000:
-        over = int((err > 30.0 * e["max"]).sum())
-        assert over <= outliers, (tag, kind, phase, field, "max", float(err.max()), 30.0 * e["max"], int(np.argmax(err)), over)
+        cap = hard_cap(e)
+        over = int((err > cap).sum())
+        assert over <= outliers, (tag, kind, phase, field, "max", float(err.max()), cap, int(np.argmax(err)), over)
         assert np.quantile(err, 0.999) <= e["max"], (tag, kind, phase, field, "p99.9", float(np.quantile(err, 0.999)), e["max"])
     else:
         assert int((err > e["max"]).sum()) <= 1, (tag, kind, phase, field, "envs above max in a small sample", np.nonzero(err > e["max"])[0].tolist(), e["max"])
