@@ -138,6 +138,13 @@ int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs);
  * No counterpart in the reference (XLA schedules its own kernels).  The Airbot kernels (work queue) ignore it. */
 int rsr_batch_set_priority(rsr_batch* b, int policy);
 
+/* action_repeat of the training wrappers (brax EpisodeWrapper(env, episode_length, action_repeat), applied at RSR/train.py:224-229 and
+ * _src/wrapper.py:41-74): one rsr_step = `repeat` env steps with the same action, reward = the sum of their rewards, steps and the
+ * episode length advance by `repeat`, done / truncation / the episode metrics are formed once from the last repeat's state, AutoReset
+ * acts after that.  1 (the default, and the only value the reference passes: RSR/train.py:81): the wrappers fused in the step kernels;
+ * 2 ... 64: the step kernels run as the plain env.step and three small kernels carry the wrappers around the repeats. */
+int rsr_batch_set_action_repeat(rsr_batch* b, int repeat);
+
 /* Health of the work queue.  A phase of an env waits for the previous phase's hand-off with a bounded spin; a wait that
  * times out is counted on the device (sticky for the batch's lifetime), the env's later phases inherit the mark, and the
  * env's stats[3] reads -1 after that step.  rsr_batch_check synchronises `hip_stream`, copies the count to

@@ -38,7 +38,7 @@ DR_FIELDS = [
 
 SYMBOLS = [
     "rsr_model_create", "rsr_model_dims", "rsr_model_destroy", "rsr_batch_create", "rsr_batch_destroy",
-    "rsr_batch_set_dr", "rsr_batch_set_dr_field", "rsr_batch_set_schedule", "rsr_batch_set_whole_envs", "rsr_batch_set_priority", "rsr_batch_check", "rsr_batch_set_fault_injection", "rsr_rollout_metrics", "rsr_reset", "rsr_step", "rsr_view", "rsr_batch_set_debug",
+    "rsr_batch_set_dr", "rsr_batch_set_dr_field", "rsr_batch_set_schedule", "rsr_batch_set_whole_envs", "rsr_batch_set_priority", "rsr_batch_set_action_repeat", "rsr_batch_check", "rsr_batch_set_fault_injection", "rsr_rollout_metrics", "rsr_reset", "rsr_step", "rsr_view", "rsr_batch_set_debug",
     "rsr_timing_begin", "rsr_timing_end", "rsr_last_error",
 ]
 
@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     L.rsr_batch_set_schedule.argtypes = [vp, i32]
     L.rsr_batch_set_whole_envs.argtypes = [vp, i32]
     L.rsr_batch_set_priority.argtypes = [vp, i32]
+    L.rsr_batch_set_action_repeat.argtypes = [vp, i32]
     L.rsr_rollout_metrics.argtypes = [vp, vp, vp]
     L.rsr_batch_check.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.rsr_batch_set_fault_injection.argtypes = [vp, i32, i32]

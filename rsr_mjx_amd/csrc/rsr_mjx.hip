@@ -1602,6 +1602,61 @@ __global__ __launch_bounds__(1024) void rollout_metrics_kernel(const float* __re
   }
   if (t == 0) { out[0] = (float)n; out[1] = red[0][0]; out[2] = red[1][0]; out[3] = red[2][0] / (float)n; }
 }
+
+// ---------------------------------------------------------------- action_repeat > 1 (brax EpisodeWrapper.step: scan of env.step)
+// The fused step kernels carry the wrappers for action_repeat = 1, the only value the reference passes (RSR/train.py:81).  For a
+// larger value rsr_step runs the step kernels `repeat` times on a copy of the model view with the wrapper flags cleared (plain
+// env.step) and these three small kernels carry the wrappers around them: the reward is the sum of the repeats' rewards in order,
+// steps and the episode length advance by `repeat`, done / truncation / episode metrics are formed once from the last repeat's
+// state, AutoReset restores the first state after that.  One wavefront per env; nothing here is on the reference's hot path.
+__global__ __launch_bounds__(64) void repeat_pre_kernel(float* __restrict__ state, Layout L, int n, int wrap_flags, float* __restrict__ racc) {
+  const int e = blockIdx.x;
+  if (e >= n || threadIdx.x != 0) return;
+  float* rec = state + (size_t)e * L.rec;
+  if ((wrap_flags & 2) != 0 && rec[L.done] != 0.0f) rec[L.steps] = 0.0f;      // AutoResetWrapper.step pre-step
+  racc[e] = 0.0f;
+}
+__global__ __launch_bounds__(256) void repeat_acc_kernel(const float* __restrict__ state, Layout L, int n, float* __restrict__ racc) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n) racc[e] += state[(size_t)e * L.rec + L.reward];
+}
+__global__ __launch_bounds__(64) void repeat_post_kernel(float* __restrict__ state, Layout L, int n, int wrap_flags, int repeat, int episode_length,
+                                                        int nmet, int obs_dim, int priv_dim, int xfrc_at, const float* __restrict__ racc) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= n) return;
+  float* rec = state + (size_t)e * L.rec;
+  const bool wrap_episode = wrap_flags & 1, wrap_autoreset = (wrap_flags & 2) != 0;
+  const float reward = racc[e];
+  float done = rec[L.done], steps = rec[L.steps];
+  const float prev_done = wrap_episode ? rec[L.episode_done] : 0.0f;
+  const float em_old = (wrap_episode && lane < nmet + 2) ? rec[L.episode_metrics + lane] : 0.0f;
+  const float met = (lane >= 2 && lane < nmet + 2) ? rec[L.metrics + lane - 2] : 0.0f;
+  bool over = false;
+  float trunc = 0.0f;
+  if (wrap_episode) {
+    steps += (float)repeat;
+    over = steps >= (float)episode_length;
+    trunc = over ? 1.0f - done : 0.0f;
+    if (lane < nmet + 2) {
+      const float add = lane == 0 ? reward : (lane == 1 ? (float)repeat : met);
+      rec[L.episode_metrics + lane] = prev_done != 0.0f ? 0.0f : em_old + add;
+    }
+  }
+  if (over) done = 1.0f;
+  __syncthreads();
+  if (lane == 0) {
+    rec[L.reward] = reward;
+    if (wrap_episode) { rec[L.truncation] = trunc; rec[L.episode_done] = done; }
+    rec[L.steps] = steps;
+    rec[L.done] = done;
+  }
+  if (wrap_autoreset && done != 0.0f) {
+    if (xfrc_at >= 0 && lane < 3) rec[L.go2_info + xfrc_at + lane] = 0.0f;      // data.xfrc_applied goes back with `data`
+    for (int t = lane; t < L.persist_end; t += 64) rec[t] = rec[L.f_qpos + t];
+    for (int t = lane; t < obs_dim; t += 64) rec[L.obs + t] = rec[L.f_obs + t];
+    for (int t = lane; t < priv_dim; t += 64) rec[L.priv_obs + t] = rec[L.f_priv_obs + t];
+  }
+}
 #endif
 
 }  // namespace rsr
@@ -1656,6 +1711,9 @@ struct rsr_batch {
   int spin_cap, withhold_env;   // rsr_batch_set_fault_injection (test hook)
   int whole_envs;               // rsr_batch_set_whole_envs: envs stepped as one unit each (-1: all but two resident rounds' worth)
   int prio_policy, prio_slots;  // rsr_batch_set_priority (-1: chosen from the batch size per launch); resident waves of the step kernel
+  int action_repeat;            // rsr_batch_set_action_repeat (1: the wrappers fused in the step kernels)
+  DModel* dmodel_plain;         // device copy of the model view with the wrapper flags cleared (action_repeat > 1), or null
+  float* racc;                  // [n] reward sums of the repeats, or null
 };
 
 static Layout make_layout(const rsr_dims& d) {
@@ -1930,6 +1988,7 @@ extern "C" int rsr_batch_create(const rsr_model* m, int num_envs, int hip_device
   if (rc) { release(); return rc; }
   b->launch_id = 0; b->units = 1; b->step_grid = 0; b->spin_cap = RSR_SPIN_CAP_DEFAULT; b->withhold_env = -1; b->whole_envs = -1;
   b->prio_policy = -1; b->prio_slots = 1;
+  b->action_repeat = 1; b->dmodel_plain = nullptr; b->racc = nullptr;
   if (m->dims.env_kind == rsr::ENV_GO2 || m->dims.env_kind == rsr::ENV_GO2_HANDSTAND) {
     int per_cu = rsr::go2_step_occupancy(m->dims.env_kind == rsr::ENV_GO2_HANDSTAND ? 1 : 0, m->has_hfield);
     hipDeviceProp_t prop;
@@ -1971,6 +2030,8 @@ extern "C" void rsr_batch_destroy(rsr_batch* b) {
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->dblob) (void)hipFree(b->dblob);
   if (b->dmodel) (void)hipFree(b->dmodel);
+  if (b->dmodel_plain) (void)hipFree(b->dmodel_plain);
+  if (b->racc) (void)hipFree(b->racc);
   if (b->sched) (void)hipFree(b->sched);
   if (b->owns_state && b->state) (void)hipFree(b->state);
   delete b;
@@ -2009,6 +2070,23 @@ extern "C" int rsr_batch_set_schedule(rsr_batch* b, int units) {
 extern "C" int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs) {
   if (!b || whole_envs > b->n) return fail(RSR_ERR_ARG, "rsr_batch_set_whole_envs: bad argument");
   b->whole_envs = whole_envs < 0 ? -1 : whole_envs;
+  return RSR_OK;
+}
+
+extern "C" int rsr_batch_set_action_repeat(rsr_batch* b, int repeat) {
+  if (!b || repeat < 1 || repeat > 64) return fail(RSR_ERR_ARG, "rsr_batch_set_action_repeat: repeat must be 1 ... 64");
+  HIPCHK(hipSetDevice(b->device));
+  if (repeat > 1 && !b->dmodel_plain) {
+    DModel plain = b->dm;
+    plain.wrap_flags = 0;
+    if (hipMalloc(&b->dmodel_plain, sizeof(DModel)) != hipSuccess) { b->dmodel_plain = nullptr; return fail(RSR_ERR_NOMEM, "rsr_batch_set_action_repeat: hipMalloc(dmodel)"); }
+    if (hipMalloc(&b->racc, (size_t)b->n * sizeof(float)) != hipSuccess) {
+      (void)hipFree(b->dmodel_plain); b->dmodel_plain = nullptr; b->racc = nullptr;
+      return fail(RSR_ERR_NOMEM, "rsr_batch_set_action_repeat: hipMalloc(reward sums)");
+    }
+    HIPCHK(hipMemcpy(b->dmodel_plain, &plain, sizeof(DModel), hipMemcpyHostToDevice));
+  }
+  b->action_repeat = repeat;
   return RSR_OK;
 }
 
@@ -2083,10 +2161,17 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
   rsr::StepArgs a = make_args(b);
   a.action = action;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int repeat = b->action_repeat;
+  const Layout& LY = b->model->layout;
+  const rsr_dims& dd = b->model->dims;
+  const DModel* dmodel = repeat > 1 ? b->dmodel_plain : b->dmodel;      // (repeat > 1: plain env.step, the wrappers around the repeats)
+  if (repeat > 1)
+    hipLaunchKernelGGL(rsr::repeat_pre_kernel, dim3(b->n), dim3(64), 0, st, b->state, LY, b->n, b->dm.wrap_flags, b->racc);
+  for (int rep = 0; rep < repeat; ++rep) {
   if (b->model->dims.env_kind == rsr::ENV_GO2)
-    rsr::launch_go2_step(b->n, st, b->dmodel, b->model->layout, a, b->model->has_hfield);
+    rsr::launch_go2_step(b->n, st, dmodel, b->model->layout, a, b->model->has_hfield);
   else if (b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND)
-    rsr::launch_hs_step(b->n, st, b->dmodel, b->model->layout, a);
+    rsr::launch_hs_step(b->n, st, dmodel, b->model->layout, a);
   else {
     ++b->launch_id;
     if ((b->launch_id & 0xFFFFFFu) == 0u) {        // the flags carry 24 bits of the launch number: clear them before the number repeats
@@ -2102,10 +2187,18 @@ extern "C" int rsr_step(rsr_batch* b, const float* action, void* hip_stream) {
     const long long work = (long long)n_whole + (long long)b->units * (b->n - n_whole);
     const int grid = (int)(work > b->step_grid ? b->step_grid : work);
     if (b->model->dims.env_kind == rsr::ENV_TSHAPE)
-      rsr::launch_tshape_step(grid, st, b->dmodel, b->model->layout, a, sc);
+      rsr::launch_tshape_step(grid, st, dmodel, b->model->layout, a, sc);
     else
       hipLaunchKernelGGL((rsr::step_kernel<rsr::CubeDims, rsr::ENV_CUBE>), dim3(grid), dim3(64), sizeof(rsr::Smem<rsr::CubeDims>), st,
-                         b->dmodel, b->model->layout, a, sc);
+                         dmodel, b->model->layout, a, sc);
+  }
+  if (repeat > 1)
+    hipLaunchKernelGGL(rsr::repeat_acc_kernel, dim3((b->n + 255) / 256), dim3(256), 0, st, b->state, LY, b->n, b->racc);
+  }
+  if (repeat > 1) {
+    const bool go2_family = dd.env_kind == rsr::ENV_GO2 || dd.env_kind == rsr::ENV_GO2_HANDSTAND;
+    hipLaunchKernelGGL(rsr::repeat_post_kernel, dim3(b->n), dim3(64), 0, st, b->state, LY, b->n, b->dm.wrap_flags, repeat, b->dm.episode_length,
+                       dd.nmetrics, dd.obs_dim, go2_family ? rsr::GO2_PRIV : 0, dd.env_kind == rsr::ENV_GO2 ? (int)rsr::G2_XFRC : -1, b->racc);
   }
   HIPCHK(hipGetLastError());
   if (b->timing) b->launches++;

@@ -248,6 +248,12 @@ class BatchedEnv:
         _lib.check(_lib.lib().rsr_rollout_metrics(self._batch, C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def set_action_repeat(self, repeat: int = 1) -> None:
+        """action_repeat of the training wrappers (brax EpisodeWrapper): one step = `repeat` env steps with the same action, rewards
+        summed, steps advanced by `repeat`, done / truncation / AutoReset once after the last (rsr_batch_set_action_repeat)."""
+        _lib.check(_lib.lib().rsr_batch_set_action_repeat(self._batch, int(repeat)))
+        self.action_repeat = int(repeat)
+
     def set_priority(self, policy: int = -1) -> None:
         """Wave priority schedule of the plain-launch step kernels (rsr_batch_set_priority: 0 off, 1 rotate, 2 catch up, -1 by batch
         size); timing only, results are bit-identical."""
@@ -362,10 +368,11 @@ def wrap(env: AirbotPlayBase, num_envs: int, episode_length: int = 1000, action_
          randomization_fn: Optional[Callable[[CompiledModel], Dict[str, Any]]] = None) -> BatchedEnv:
     """Counterpart of brax.envs.training.wrap as called at reference RSR/train.py:224-229:
     Vmap | DomainRandomizationVmap -> Episode -> AutoReset, fused into the step kernel."""
-    if action_repeat != 1:
-        raise NotImplementedError("action_repeat != 1 (the reference trains with action_repeat=1, train.py:47)")
     dr = randomization_fn(env.sys) if randomization_fn is not None else None
-    return env.batched(num_envs, episode_length=episode_length, auto_reset=True, randomization=dr)
+    benv = env.batched(num_envs, episode_length=episode_length, auto_reset=True, randomization=dr)
+    if action_repeat != 1:          # (the reference trains with action_repeat = 1, train.py:47: the wrappers fused in the step kernel)
+        benv.set_action_repeat(action_repeat)
+    return benv
 
 
 def wrap_sub_batches(env, num_envs: int, parts: int, episode_length: int = 1000, action_repeat: int = 1,
@@ -374,8 +381,6 @@ def wrap_sub_batches(env, num_envs: int, parts: int, episode_length: int = 1000,
     sub-batch on separate HIP streams (rollout.generate_unroll_pipelined, bench.py `sub_batched`): one sub-batch's launch
     tail is then hidden behind the other's next launch.  Env i is the same env as in `wrap`: keys and
     randomised leaves are sliced by index.  Works for every env definition with a `batched` method (Airbot, Go2)."""
-    if action_repeat != 1:
-        raise NotImplementedError("action_repeat != 1")
     if num_envs % parts:
         raise ValueError("num_envs must be a multiple of parts")
     m = num_envs // parts
@@ -384,6 +389,8 @@ def wrap_sub_batches(env, num_envs: int, parts: int, episode_length: int = 1000,
     for k in range(parts):
         sub = None if dr is None else {f: v[k * m:(k + 1) * m] for f, v in dr.items()}
         out.append(env.batched(m, episode_length=episode_length, auto_reset=True, randomization=sub))
+        if action_repeat != 1:
+            out[-1].set_action_repeat(action_repeat)
     return out
 
 

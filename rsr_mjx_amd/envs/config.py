@@ -181,8 +181,7 @@ GO2_PRIV_OBS_DIM = 123      # obs["privileged_state"], joystick.py:341-366
 
 def go2_env_fields(m: CompiledModel, config: dict, episode_length: int = 0, auto_reset: bool = False) -> Dict[str, np.ndarray]:
     """`m` must already carry the base.py overrides (go2_apply_overrides)."""
-    if config["action_repeat"] != 1:
-        raise NotImplementedError("action_repeat != 1")
+    # (config["action_repeat"] is the trainer's: it reaches the Episode wrapper through wrap_for_brax_training, not the env)
     A = m.arrays
     n_sub = int(round(config["ctrl_dt"] / config["sim_dt"]))      # _src/mjx_env.py:139-142
     home = A["key_qpos"][m.names["key"]["home"]].astype(np.float32)
@@ -247,8 +246,7 @@ def handstand_env_fields(m: CompiledModel, config: dict, episode_length: int = 0
     env_go2f: ctrl_dt, action_scale, noise level, scales joint_pos / joint_vel / gyro / gravity / linvel, init_from_crouch,
     energy_termination_threshold, z_des, desired forward vector (3).  env_go2i: joint ids of the pose cost.  env_go2_scales: the eleven
     reward scales in config order.  env_go2_home: home qpos | pre_recovery qpos.  env_go2_soft: soft lower | soft upper limits."""
-    if config["action_repeat"] != 1:
-        raise NotImplementedError("action_repeat != 1")
+    # (config["action_repeat"] is the trainer's: it reaches the Episode wrapper through wrap_for_brax_training, not the env)
     unwanted, feet, joint_ids, fwd, z_des = _HANDSTAND_VARIANTS[variant]
     A = m.arrays
     n_sub = int(round(config["ctrl_dt"] / config["sim_dt"]))

@@ -134,11 +134,11 @@ class Go2Batched(BatchedEnv):
 def wrap_for_brax_training(env: Joystick, num_envs: int, episode_length: int = 1000, action_repeat: int = 1,
                            randomization_fn=None) -> Go2Batched:
     """Counterpart of reference _src/wrapper.py:41-74 (Vmap -> Episode -> AutoReset), fused into the step kernel."""
-    if action_repeat != 1:
-        raise NotImplementedError("action_repeat != 1")
     benv = env.batched(num_envs, episode_length=episode_length, auto_reset=True)
     if randomization_fn is not None:
         benv.set_randomization(randomization_fn(env.sys))     # the per-env leaves of MjxDomainRandomizationVmapWrapper (wrapper.py:107-138)
+    if action_repeat != 1:          # wrapper.py:69: brax EpisodeWrapper(env, episode_length, action_repeat)
+        benv.set_action_repeat(action_repeat)
     return benv
 
 

@@ -529,3 +529,65 @@ def test_wave_priority_policies_are_bit_identical(task, nu):
     assert float(a.view("info_steps").max()) <= 7.0
     with pytest.raises(Exception):
         b.set_priority(3)
+
+
+@pytest.mark.gpu
+def test_go2_action_repeat_on_device(oracle_mod):
+    """rsr_batch_set_action_repeat on the Go2 joystick (reference _src/wrapper.py:69: brax EpisodeWrapper(env, episode_length,
+    action_repeat)): repeat 2, episode_length 6, falls forced on a third of the envs.  HIP (plain step kernel twice + the wrapper
+    kernels) against the PLAIN oracle env under the numpy restatement of the wrapper (tests/test_parity_gpu.py::_np_repeat_step),
+    teacher-forced per outer step.  Counters exact; reward = the two rewards summed; where done, the cached first state -- pipeline
+    state, obs, privileged obs -- is back bit for bit and data.xfrc_applied is zero; the info block is never reset."""
+    import torch
+    from rsr_mjx_amd.envs import go2
+    from test_parity_gpu import _np_repeat_step
+    n, L, repeat = 1024, 6, 2
+    jenv = go2.load("Go2JoystickFlatTerrain")
+    env = go2.wrap_for_brax_training(jenv, n, episode_length=L, action_repeat=repeat)
+    orc_w = oracle_mod.Oracle(env.blob); orc_w.set_ncon_cap(env.dims.ncon_max)
+    orc_p = oracle_mod.Oracle(jenv.batched(4).blob); orc_p.set_ncon_cap(env.dims.ncon_max)
+    keys = prng.split(prng.PRNGKey(43), n)
+    st = orc_w.new_state(n); orc_w.reset(st, keys)
+    state = env.reset(keys)
+    torch.cuda.synchronize()
+    gname = {"priv_obs": "privileged_obs", "first_priv_obs": "first_privileged_obs"}
+    get = lambda k: env.view(gname.get(k, k)).cpu().numpy().reshape(st[k].shape)
+    fields = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs", "reward", "done", "metrics", "info_go2",
+              "info_steps", "info_truncation", "info_episode_done", "info_episode_metrics", "first_qpos", "first_qvel", "first_ctrl",
+              "first_warmstart", "first_time", "first_xpos", "first_site_xpos", "first_obs", "priv_obs", "first_priv_obs"]
+    serr = lambda a, b: (np.abs(a.astype(np.float64) - b).reshape(n, -1) / np.maximum(1.0, np.abs(b.astype(np.float64)).reshape(n, -1).max(1, keepdims=True))).max(1)
+    pipeline = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs"]
+    rng = np.random.default_rng(43)
+    first_obs, first_priv, first_qpos = st["first_obs"].copy(), st["first_priv_obs"].copy(), st["first_qpos"].copy()
+    saw_fall = saw_trunc = 0
+    for t in range(1, 3 * L // repeat + 2):
+        if t == 2:                      # flip a third of the trunks upside down: the env's own termination (joystick.py: up[2] < 0)
+            st["qpos"][::3, 3:7] = np.array([0.0, 1.0, 0.0, 0.0], dtype=f32)
+        for k in fields:
+            env.view(gname.get(k, k)).copy_(torch.from_numpy(st[k].reshape(n, -1)))
+        a = np.clip(rng.normal(size=(n, 12)) * 0.5, -1, 1).astype(f32)
+        _np_repeat_step(orc_p, st, a, repeat, L, pipeline, extra_restore=[("priv_obs", "first_priv_obs")])
+        st["info_go2"][st["done"] != 0, 139:142] = 0.0                       # data.xfrc_applied goes back with `data`
+        state = env.step(state, a)
+        torch.cuda.synchronize()
+        for k in ("done", "info_steps", "info_truncation", "info_episode_done", "time"):
+            np.testing.assert_array_equal(get(k), st[k], err_msg=f"{k} at outer step {t}")
+        np.testing.assert_array_equal(_key(get("info_go2")), _key(st["info_go2"]))               # two in-step key splits per outer step
+        done = st["done"] != 0
+        e_r = serr(get("reward"), st["reward"])
+        assert np.quantile(e_r, 0.99) <= 1e-4 and np.mean(e_r > 0.05) <= 0.005, (t, float(np.quantile(e_r, 0.99)), float(e_r.max()))
+        e_o = serr(get("obs"), st["obs"])
+        lim = max(PE.bound("go2", "reset", "obs"), PE.bound("go2", "rollout", "obs"))
+        if (~done).any():
+            assert np.quantile(e_o[~done], 0.95) <= lim, (t, float(np.quantile(e_o[~done], 0.95)), lim)
+        em = serr(get("info_episode_metrics"), st["info_episode_metrics"])
+        assert np.quantile(em, 0.99) <= 2e-4 and np.mean(em > 0.05) <= 0.005, (t, float(np.quantile(em, 0.99)), float(em.max()))
+        np.testing.assert_array_equal(get("info_episode_metrics")[:, 1], st["info_episode_metrics"][:, 1])     # episode length: += repeat
+        if done.any():
+            np.testing.assert_array_equal(get("obs")[done], first_obs[done])
+            np.testing.assert_array_equal(get("priv_obs")[done], first_priv[done])
+            np.testing.assert_array_equal(get("qpos")[done], first_qpos[done])
+            assert not get("info_go2")[done][:, 139:142].any()
+        saw_fall += int((done & (st["info_truncation"] == 0)).sum())
+        saw_trunc += int((st["info_truncation"] != 0).sum())
+    assert saw_fall >= n // 3 and saw_trunc >= n, (saw_fall, saw_trunc)

@@ -598,3 +598,113 @@ def test_envelopes_were_measured_on_these_kernel_sources():
     import bench
     assert PE.ENV["_provenance"]["csrc_sha16"] == bench.csrc_sha16(), (
         "parity envelopes were measured on other kernel sources: re-run tools/gpu_parity_stats.py --json and tools/make_parity_envelopes.py")
+
+
+def _np_repeat_step(orc_plain, st, act, repeat, L, pipeline, extra_restore=()):
+    """brax EpisodeWrapper.step with action_repeat (scan of env.step, rewards summed, steps += repeat, done / truncation and the
+    episode metrics once from the last state) inside AutoResetWrapper.step (steps <- 0 where done before; the cached first state
+    where done after), restated in numpy around the PLAIN oracle env (wrapper flags 0)."""
+    f32 = np.float32
+    st["info_steps"][st["done"] != 0] = 0                                   # AutoResetWrapper.step, pre-step
+    racc = np.zeros_like(st["reward"])
+    for _ in range(repeat):
+        orc_plain.step(st, act)
+        racc = (racc + st["reward"]).astype(f32)
+    st["reward"][...] = racc
+    steps = st["info_steps"] + repeat
+    over = steps >= L
+    done = st["done"].copy()
+    prev = st["info_episode_done"].copy()
+    em = st["info_episode_metrics"]
+    em[:, 0] = np.where(prev != 0, 0, (em[:, 0] + racc).astype(f32))
+    em[:, 1] = np.where(prev != 0, 0, em[:, 1] + f32(repeat))
+    em[:, 2:] = np.where(prev[:, None] != 0, 0, (em[:, 2:] + st["metrics"].reshape(len(prev), -1)).astype(f32))
+    st["info_truncation"][...] = np.where(over, 1 - done, 0)
+    done = np.where(over, 1, done).astype(done.dtype)
+    st["info_steps"][...] = steps
+    st["done"][...] = done
+    st["info_episode_done"][...] = done
+    sel = done != 0
+    for k in pipeline:                                                      # AutoResetWrapper.step, post-step
+        fk = "first_warmstart" if k == "qacc_warmstart" else "first_" + k
+        st[k][sel] = st[fk][sel]
+    for k, fk in extra_restore:
+        st[k][sel] = st[fk][sel]
+
+
+class _HipPlainEnv:
+    """env.step of the plain (unwrapped) HIP env on a numpy state dict: push, one fused step, pull."""
+
+    def __init__(self, env, fields):
+        self.env, self.fields = env, fields
+
+    def step(self, st, act):
+        import torch
+        for k in self.fields:
+            self.env.view(k).copy_(torch.from_numpy(st[k].reshape(st[k].shape[0], -1)))
+        self.env.step(None, act)
+        torch.cuda.synchronize()
+        for k in self.fields:
+            st[k][...] = _np(self.env, k, st[k])
+
+
+@pytest.mark.parametrize("repeat", [2, 3])
+def test_action_repeat_on_device(oracle_mod, repeat):
+    """include/rsr_mjx.h, rsr_batch_set_action_repeat (brax EpisodeWrapper(env, episode_length, action_repeat), RSR/train.py:224-229):
+    episode_length 6 with repeats of 2 and 3, so truncation falls on an outer step, over three truncation boundaries.
+    (a) The wrapper kernels, bit for bit: the batch with action_repeat against the numpy restatement of the wrapper
+        (_np_repeat_step) around the PLAIN HIP env stepped `repeat` times -- same physics kernels, so every field of the record
+        must agree exactly, the reward being the repeats' rewards summed in order.
+    (b) The independent side: the same restatement around the plain ORACLE env, teacher-forced per outer step -- counters exact;
+        obs / reward within the envelopes' scale (the repeats run open-loop, and straight after reset the arm's ill-conditioned
+        solve separates any two fp32 steppers by 1e-2 in qvel: DESIGN.md 2)."""
+    import torch
+    from rsr_mjx_amd import prng
+    from rsr_mjx_amd.envs.airbot import AirbotPlayBase, wrap
+    n, L = 1024, 6
+    envdef = AirbotPlayBase(device="cuda:0")
+    env = wrap(envdef, n, episode_length=L, action_repeat=repeat)
+    env_o = wrap(envdef, n, episode_length=L, action_repeat=repeat)        # (b): teacher-forced from the oracle side
+    plain = envdef.batched(n)
+    orc_w = oracle_mod.Oracle(env.blob)                                     # reset with the wrappers' bookkeeping
+    orc_p = oracle_mod.Oracle(plain.blob)                                   # plain env.step
+    orc_p.set_ncon_cap(env.dims.ncon_max)                                   # (the oracle's switches are library-wide: set, not assumed)
+    keys = prng.split(prng.PRNGKey(31), n)
+    st = orc_w.new_state(n)
+    orc_w.reset(st, keys)
+    env.reset(keys); env_o.reset(keys); plain.reset(keys)
+    torch.cuda.synchronize()
+    carried = SHARED + ["info_last_action"]
+    hs = {k: (v.copy() if v is not None else None) for k, v in st.items()}
+    for k in carried:
+        hs[k][...] = _np(env, k, hs[k])
+    hip_plain = _HipPlainEnv(plain, carried)
+    rng = np.random.default_rng(31)
+    pipeline = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs"]
+    for t in range(1, 3 * L // repeat + 2):
+        act = rng.uniform(-1, 1, (n, 5)).astype(np.float32)
+        # (a)
+        _np_repeat_step(hip_plain, hs, act, repeat, L, pipeline)
+        env.step(None, act)
+        torch.cuda.synchronize()
+        for k in carried:
+            np.testing.assert_array_equal(_np(env, k, hs[k]).view(np.int32), hs[k].view(np.int32), err_msg=f"(a) {k} at outer step {t}")
+        # (b)
+        _push(env_o, st)
+        _np_repeat_step(orc_p, st, act, repeat, L, pipeline)
+        state = env_o.step(None, act)
+        torch.cuda.synchronize()
+        for k in EXACT:
+            np.testing.assert_array_equal(_np(env_o, k, st[k]), st[k], err_msg=f"(b) {k} at outer step {t}")
+        np.testing.assert_array_equal(_np(env_o, "info_episode_metrics", st["info_episode_metrics"])[:, 1], st["info_episode_metrics"][:, 1])
+        e_r = _scaled_err(_np(env_o, "reward", st["reward"]), st["reward"])
+        e_o = _scaled_err(_np(env_o, "obs", st["obs"]), st["obs"])
+        lim = max(PE.bound("cube", "reset", "obs"), PE.bound("cube", "rollout", "obs"))
+        assert np.quantile(e_o, 0.99) <= lim and np.quantile(e_r, 0.99) <= 1e-3, (t, float(np.quantile(e_o, 0.99)), float(np.quantile(e_r, 0.99)))
+        if (t * repeat) % L == 0:
+            assert float(state.done.min()) == 1.0 and float(state.info["truncation"].min()) == 1.0
+            np.testing.assert_array_equal(_np(env_o, "qpos", st["qpos"]), _np(env_o, "first_qpos", st["qpos"]))
+            np.testing.assert_array_equal(_np(env_o, "obs", st["obs"]), _np(env_o, "first_obs", st["obs"]))
+    assert int(st["info_steps"].max()) <= L and int(st["info_episode_metrics"][:, 1].max()) <= L
+    with pytest.raises(RuntimeError):
+        env.set_action_repeat(0)
