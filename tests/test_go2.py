@@ -540,7 +540,7 @@ def test_go2_action_repeat_on_device(oracle_mod):
     state, obs, privileged obs -- is back bit for bit and data.xfrc_applied is zero; the info block is never reset."""
     import torch
     from rsr_mjx_amd.envs import go2
-    from test_parity_gpu import _np_repeat_step
+    from wrappers_np import np_repeat_step as _np_repeat_step
     n, L, repeat = 1024, 6, 2
     jenv = go2.load("Go2JoystickFlatTerrain")
     env = go2.wrap_for_brax_training(jenv, n, episode_length=L, action_repeat=repeat)

@@ -356,3 +356,49 @@ def test_oracle_under_address_and_undefined_sanitizers(tmp_path):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sanitised oracle ok" in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
+
+
+def test_numpy_wrappers_match_the_oracle_wrappers(cube_model, go2_model, oracle_mod):
+    """tests/wrappers_np.py (the reference side of the action_repeat GPU tests) against the oracle's own C wrappers at
+    action_repeat = 1: the numpy restatement around the PLAIN oracle env must reproduce the wrapped oracle env bit for bit -- every
+    field, across two truncation boundaries and (Go2) forced falls -- and at action_repeat = 2 an outer step is two plain steps with
+    the rewards summed, steps and the episode length advanced by two."""
+    from conftest import make_go2_blob
+    from wrappers_np import np_repeat_step
+    L = 5
+    pipeline = ["qpos", "qvel", "ctrl", "qacc_warmstart", "time", "xpos", "site_xpos", "obs"]
+    cases = [("cube", make_blob(cube_model, episode_length=L, auto_reset=True), make_blob(cube_model), 5, 1.0, 24, ()),
+             ("go2", make_go2_blob(go2_model, episode_length=L, auto_reset=True), make_go2_blob(go2_model), 12, 0.5, 4, [("priv_obs", "first_priv_obs")])]
+    for kind, blob_w, blob_p, nu, astd, cap, extra in cases:
+        orc_w, orc_p = oracle_mod.Oracle(blob_w), oracle_mod.Oracle(blob_p)
+        orc_w.set_ncon_cap(cap)
+        n = 12
+        keys = prng.split(prng.PRNGKey(15), n)
+        a_st = orc_w.new_state(n); orc_w.reset(a_st, keys)
+        b_st = {k: (v.copy() if v is not None else None) for k, v in a_st.items()}
+        rng = np.random.default_rng(15)
+        for t in range(1, 2 * L + 3):
+            if kind == "go2" and t == 3:        # a fall: trunk upside down on a third of the envs (the env's own termination)
+                for s_ in (a_st, b_st):
+                    s_["qpos"][::3, 3:7] = np.array([0.0, 1.0, 0.0, 0.0], dtype=np.float32)
+            act = np.clip(rng.normal(size=(n, nu)) * astd, -1, 1).astype(np.float32)
+            orc_w.step(a_st, act)
+            np_repeat_step(orc_p, b_st, act, 1, L, pipeline, extra_restore=extra)
+            if kind == "go2":
+                b_st["info_go2"][b_st["done"] != 0, 139:142] = 0.0
+            for k, v in a_st.items():
+                if v is not None and k != "stats":
+                    np.testing.assert_array_equal(v.view(np.int32), b_st[k].view(np.int32), err_msg=f"{kind} {k} at step {t}")
+        # action_repeat = 2 from here: two plain steps per outer step
+        c_st = {k: (v.copy() if v is not None else None) for k, v in b_st.items()}
+        act = np.clip(rng.normal(size=(n, nu)) * astd, -1, 1).astype(np.float32)
+        steps0, len0, prev = b_st["info_steps"].copy(), b_st["info_episode_metrics"][:, 1].copy(), b_st["info_episode_done"].copy()
+        steps0[b_st["done"] != 0] = 0
+        np_repeat_step(orc_p, b_st, act, 2, 10 ** 6, pipeline, extra_restore=extra)
+        c_st["info_steps"][c_st["done"] != 0] = 0
+        orc_p.step(c_st, act); r1 = c_st["reward"].copy()
+        orc_p.step(c_st, act); r2 = c_st["reward"].copy()
+        np.testing.assert_array_equal(b_st["reward"], (r1 + r2).astype(np.float32))
+        np.testing.assert_array_equal(b_st["info_steps"], steps0 + 2)
+        np.testing.assert_array_equal(b_st["info_episode_metrics"][:, 1], np.where(prev != 0, 0, len0 + 2))
+        np.testing.assert_array_equal(b_st["obs"], c_st["obs"])

@@ -600,36 +600,7 @@ def test_envelopes_were_measured_on_these_kernel_sources():
         "parity envelopes were measured on other kernel sources: re-run tools/gpu_parity_stats.py --json and tools/make_parity_envelopes.py")
 
 
-def _np_repeat_step(orc_plain, st, act, repeat, L, pipeline, extra_restore=()):
-    """brax EpisodeWrapper.step with action_repeat (scan of env.step, rewards summed, steps += repeat, done / truncation and the
-    episode metrics once from the last state) inside AutoResetWrapper.step (steps <- 0 where done before; the cached first state
-    where done after), restated in numpy around the PLAIN oracle env (wrapper flags 0)."""
-    f32 = np.float32
-    st["info_steps"][st["done"] != 0] = 0                                   # AutoResetWrapper.step, pre-step
-    racc = np.zeros_like(st["reward"])
-    for _ in range(repeat):
-        orc_plain.step(st, act)
-        racc = (racc + st["reward"]).astype(f32)
-    st["reward"][...] = racc
-    steps = st["info_steps"] + repeat
-    over = steps >= L
-    done = st["done"].copy()
-    prev = st["info_episode_done"].copy()
-    em = st["info_episode_metrics"]
-    em[:, 0] = np.where(prev != 0, 0, (em[:, 0] + racc).astype(f32))
-    em[:, 1] = np.where(prev != 0, 0, em[:, 1] + f32(repeat))
-    em[:, 2:] = np.where(prev[:, None] != 0, 0, (em[:, 2:] + st["metrics"].reshape(len(prev), -1)).astype(f32))
-    st["info_truncation"][...] = np.where(over, 1 - done, 0)
-    done = np.where(over, 1, done).astype(done.dtype)
-    st["info_steps"][...] = steps
-    st["done"][...] = done
-    st["info_episode_done"][...] = done
-    sel = done != 0
-    for k in pipeline:                                                      # AutoResetWrapper.step, post-step
-        fk = "first_warmstart" if k == "qacc_warmstart" else "first_" + k
-        st[k][sel] = st[fk][sel]
-    for k, fk in extra_restore:
-        st[k][sel] = st[fk][sel]
+from wrappers_np import np_repeat_step as _np_repeat_step      # brax EpisodeWrapper / AutoResetWrapper restated in numpy
 
 
 class _HipPlainEnv:
