@@ -43,6 +43,21 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
 
 
+def reset_switches() -> None:
+    """The oracle's switches (contact capacity, culling, line-search rule and cycle cut) are variables of the shared library, not of
+    an Oracle object: back to the defaults in both builds (tests/conftest.py calls this before every test, so that no test inherits
+    what another one set)."""
+    for precision in ("f32", "f64"):
+        path = os.path.join(_HERE, f"liboracle_{precision}.so")
+        if os.path.exists(path):
+            lib = C.CDLL(path)
+            lib.oracle_set_ncon_cap(1 << 20)
+            lib.oracle_set_cull(1)
+            lib.oracle_set_ls_rule.argtypes = [C.c_int, C.c_double]
+            lib.oracle_set_ls_rule(0, 1.0)
+            lib.oracle_set_ls_cycle(0)
+
+
 def _load(precision: str) -> C.CDLL:
     path = os.path.join(_HERE, f"liboracle_{precision}.so")
     if not os.path.exists(path):

@@ -24,6 +24,14 @@ def cube_model():
     return CompiledModel.load(os.path.join(ASSETS, "airbot_cube.npz"))
 
 
+@pytest.fixture(autouse=True)
+def _oracle_defaults():
+    """The oracle's switches are library-wide: every test starts from the defaults and sets what it needs."""
+    from oracle import oracle as O
+    O.reset_switches()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as O

@@ -371,7 +371,6 @@ def test_numpy_wrappers_match_the_oracle_wrappers(cube_model, go2_model, oracle_
              ("go2", make_go2_blob(go2_model, episode_length=L, auto_reset=True), make_go2_blob(go2_model), 12, 0.5, 4, [("priv_obs", "first_priv_obs")])]
     for kind, blob_w, blob_p, nu, astd, cap, extra in cases:
         orc_w, orc_p = oracle_mod.Oracle(blob_w), oracle_mod.Oracle(blob_p)
-        orc_w.set_ncon_cap(cap)
         n = 12
         keys = prng.split(prng.PRNGKey(15), n)
         a_st = orc_w.new_state(n); orc_w.reset(a_st, keys)
