@@ -134,7 +134,8 @@ int rsr_batch_set_whole_envs(rsr_batch* b, int whole_envs);
  *   1  rotate: (wave slot + substep) mod 4 -- waves that start together take turns and finish together;
  *   2  catch up: least progress first, and the waves of the launch's final resident set keep a floor that grows with their
  *      start time, so that the set finishes together instead of draining one wave per SIMD at a time;
- *  -1  (default) joystick kernels: 1 for a batch of at most one resident round of envs (4096 on MI355X), 2 above; handstand: 1.
+ *  -1  (default) joystick kernels: 1 for a batch of at most one resident round of envs (4096 on MI355X), 0 up to 13/8 of a round
+ *      (few late starters: measured), 2 above; handstand: 1.
  * No counterpart in the reference (XLA schedules its own kernels).  The Airbot kernels (work queue) ignore it. */
 int rsr_batch_set_priority(rsr_batch* b, int policy);
 

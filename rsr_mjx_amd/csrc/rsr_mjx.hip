@@ -2128,10 +2128,12 @@ static rsr::StepArgs make_args(rsr_batch* b) {
   a.dr_geom_friction = b->dr_fric; a.dr_body_mass = b->dr_mass; a.dr_dof_damping = b->dr_damp; a.dr_dof_frictionloss = b->dr_floss;
   a.dr_body_ipos = b->dr_ex[0]; a.dr_qpos0 = b->dr_ex[1]; a.dr_dof_armature = b->dr_ex[2]; a.dr_gainprm = b->dr_ex[3]; a.dr_biasprm = b->dr_ex[4];
   a.debug = b->debug;
-  // default: waves that start together take turns; a joystick batch of more than one resident round lets its late starters catch up
-  // (measured per kernel family and batch size: DESIGN.md 4)
+  // default: waves that start together take turns; a joystick batch of more than one resident round lets its late starters catch up,
+  // except when they are few (up to 5/8 of a round beyond the first: the slots the oldest-first arbitration frees early are worth more
+  // than an even finish there -- 5120 / 6144 envs on 4096 slots lose 3.5 / 2 % under either policy, 7168 gain 9 %: DESIGN.md 4)
   const bool rotate = b->model->dims.env_kind == rsr::ENV_GO2_HANDSTAND || b->n <= b->prio_slots;
-  a.prio_mode = b->prio_policy >= 0 ? b->prio_policy : (rotate ? rsr::RSR_PRIO_ROTATE : rsr::RSR_PRIO_CATCH_UP);
+  const bool few_late = !rotate && (long long)b->n * 8 < (long long)b->prio_slots * 13;
+  a.prio_mode = b->prio_policy >= 0 ? b->prio_policy : (rotate ? rsr::RSR_PRIO_ROTATE : (few_late ? rsr::RSR_PRIO_OFF : rsr::RSR_PRIO_CATCH_UP));
   a.prio_slots = b->prio_slots;
   return a;
 }
